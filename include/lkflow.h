@@ -1,0 +1,149 @@
+/*
+ * lkflow.h -- C ABI of the MI355X dense pyramidal Lucas-Kanade engine (liblkflow.so).
+ *
+ * Drop-in boundary for the ONE hot call of mileslindheimer/optical-flow:
+ *
+ *     void coarseToFineEstimation(Mat &img1, Mat &img2, Mat &u, Mat &v, int nLevels)
+ *         ParallelVideoPyr.cpp:578 (OpenMP)   SerialPyr.cpp:157 (serial ground truth)
+ *         called from the video loop at ParallelVideoPyr.cpp:832 and the still-image
+ *         harness at ParallelBasicPyr.cpp:753
+ *     void getLucasKanadeOpticalFlow(Mat &img1, Mat &img2, Mat &u, Mat &v)
+ *         ParallelVideoPyr.cpp:327   SerialPyr.cpp:121
+ *     int  getMaxLayer(Mat &img)      ParallelVideoPyr.cpp:545   SerialPyr.cpp:196
+ *
+ * The reference has no FFI; these entry points are what a binding for that call would bind
+ * (plain pointers and sizes, no C++ / torch / OpenCV types).  include/lkflow.hpp wraps them in
+ * the reference's own C++ signatures (cv::Mat-compatible) -- see INTEGRATION.md.
+ *
+ * All image planes are CV_64FC1: fp64, row-major, "step" = bytes between rows (>= cols*8,
+ * multiple of 8).  Every function returns LKFLOW_OK (0) or a negative lkflow_status.
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with
+ * LKFLOW_E_NODEVICE / LKFLOW_E_HIP.
+ */
+#ifndef LKFLOW_H
+#define LKFLOW_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum lkflow_status {
+    LKFLOW_OK = 0,
+    LKFLOW_E_ARG = -1,      /* null pointer, rows/cols < 1, bad step, n_pairs < 1, bad flags      */
+    LKFLOW_E_LEVELS = -2,   /* pyr_levels < 1 or > lkflow_max_levels(cols, rows)                   */
+                            /*   (the reference throws cv::Exception at "tmpu += upu", :635)       */
+    LKFLOW_E_WIN = -3,      /* win even, < 3 or > LKFLOW_MAX_WIN                                   */
+    LKFLOW_E_HIP = -4,      /* a HIP runtime call failed (see lkflow_last_error)                   */
+    LKFLOW_E_NOMEM = -5,    /* device workspace allocation failed                                  */
+    LKFLOW_E_NODEVICE = -6  /* no HIP device / bad device index                                    */
+} lkflow_status;
+
+#define LKFLOW_MAX_WIN 31
+
+/* flags */
+#define LKFLOW_MUTATE_INPUTS 1u /* write the level-0 warped images back into prev/next exactly as
+                                   the reference overwrites pyr[0] (ParallelVideoPyr.cpp:568,696,701).
+                                   Default (0): inputs are left untouched, so frame pairs are
+                                   independent and can be batched / sharded.  Only with n_pairs==1. */
+
+typedef struct lkflow_ctx lkflow_ctx;
+
+/* getMaxLayer (ParallelVideoPyr.cpp:545-564): the largest legal pyr_levels for cols x rows. */
+int lkflow_max_levels(int cols, int rows);
+
+const char *lkflow_strerror(int status);
+/* Text of the last HIP error seen by this context ("" if none). */
+const char *lkflow_last_error(const lkflow_ctx *ctx);
+/* Library version string. */
+const char *lkflow_version(void);
+
+/* One context per GPU and caller thread: owns the device workspace (pyramids, per-level flow). */
+int lkflow_ctx_create(lkflow_ctx **out, int device);
+void lkflow_ctx_destroy(lkflow_ctx *ctx);
+/* Optional: size the workspace up front (needed before HIP-graph capture; otherwise it grows
+ * lazily with a stream-synchronising reallocation). */
+int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int n_pairs);
+/* Tuning / debug knobs (never needed for correctness). */
+#define LKFLOW_OPT_IMPL 1      /* 0 = tiled marching kernels (default), 1 = per-pixel cross-check kernels */
+#define LKFLOW_OPT_TILE_ROWS 2 /* output rows per LK block; 0 = automatic */
+int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value);
+/* Bytes of device workspace currently held. */
+size_t lkflow_ctx_workspace_bytes(const lkflow_ctx *ctx);
+
+/*
+ * coarseToFineEstimation on HOST buffers (the cv::Mat drop-in, ParallelVideoPyr.cpp:578):
+ * copies prev/next to the GPU, runs the pyramid, copies U/V back, synchronises.
+ * prev/next are only written when flags has LKFLOW_MUTATE_INPUTS.
+ */
+int lkflow_compute_f64(lkflow_ctx *ctx, double *prev, double *next, int rows, int cols,
+                       size_t step_bytes, double *U, double *V, size_t uv_step_bytes,
+                       int pyr_levels, int win, unsigned flags);
+
+/* getLucasKanadeOpticalFlow on HOST buffers (ParallelVideoPyr.cpp:327), window generalised. */
+int lkflow_lk_f64(lkflow_ctx *ctx, const double *img1, const double *img2, int rows, int cols,
+                  size_t step_bytes, double *U, double *V, size_t uv_step_bytes, int win);
+
+/*
+ * Device-resident, batched, asynchronous form (what the video loop / bench uses):
+ * pair p reads  prev + p*prev_pair_stride_bytes , next + p*next_pair_stride_bytes
+ *        writes U + p*uv_pair_stride_bytes , V + p*uv_pair_stride_bytes.
+ * A video of F frames with frame stride S is F-1 pairs with prev = frames, next = frames + S,
+ * both pair strides = S.  All pointers are DEVICE pointers on the context's GPU.  Work is
+ * enqueued on `stream` (a hipStream_t, NULL = default stream); the call does not synchronise.
+ */
+int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next,
+                                 size_t prev_pair_stride_bytes, size_t next_pair_stride_bytes,
+                                 int n_pairs, int rows, int cols, size_t step_bytes, double *U,
+                                 double *V, size_t uv_pair_stride_bytes, size_t uv_step_bytes,
+                                 int pyr_levels, int win, unsigned flags, void *stream);
+
+/* Single-level LK, device-resident, batched (same addressing rules). */
+int lkflow_lk_batch_f64_dev(lkflow_ctx *ctx, const double *img1, const double *img2,
+                            size_t img1_pair_stride_bytes, size_t img2_pair_stride_bytes,
+                            int n_pairs, int rows, int cols, size_t step_bytes, double *U, double *V,
+                            size_t uv_pair_stride_bytes, size_t uv_step_bytes, int win, void *stream);
+
+/* ---- stage entry points (device pointers, n_planes contiguous-or-strided planes) ------------
+ * Exposed so that every kernel can be parity-tested against the oracle in isolation. */
+
+/* cv::pyrDown (ParallelVideoPyr.cpp:571): dst is ((rows+1)/2) x ((cols+1)/2). */
+int lkflow_pyrdown_f64_dev(lkflow_ctx *ctx, const double *src, size_t src_plane_stride_bytes,
+                           int n_planes, int rows, int cols, size_t src_step_bytes, double *dst,
+                           size_t dst_plane_stride_bytes, size_t dst_step_bytes, void *stream);
+
+/* cv::pyrUp (ParallelVideoPyr.cpp:646-647): dst is (2*rows) x (2*cols). */
+int lkflow_pyrup_f64_dev(lkflow_ctx *ctx, const double *src, size_t src_plane_stride_bytes,
+                         int n_planes, int rows, int cols, size_t src_step_bytes, double *dst,
+                         size_t dst_plane_stride_bytes, size_t dst_step_bytes, void *stream);
+
+/*
+ * pyrUp + map build + remap of both images (ParallelVideoPyr.cpp:646-703):
+ * (cu,cv) is the coarse flow, (rows/2) x (cols/2); img1/img2 are rows x cols (both even);
+ * out1 = remap(img1, (x,y) + up(c)/2), out2 = remap(img2, (x,y) - up(c)/2).  out may not alias in.
+ */
+int lkflow_warp_f64_dev(lkflow_ctx *ctx, const double *img1, const double *img2,
+                        size_t img_plane_stride_bytes, int n_pairs, int rows, int cols,
+                        size_t img_step_bytes, const double *cu, const double *cv,
+                        size_t c_plane_stride_bytes, size_t c_step_bytes, double *out1, double *out2,
+                        size_t out_plane_stride_bytes, size_t out_step_bytes, void *stream);
+
+/* convertTo(CV_64FC1, 1.0/255) (SerialPyr.cpp:237) for n contiguous bytes. */
+int lkflow_u8_to_f64_dev(lkflow_ctx *ctx, const unsigned char *src, double *dst, size_t n,
+                         void *stream);
+
+/*
+ * Flow consumer of the video loop (ParallelVideoPyr.cpp:845-873), batched and fused:
+ * for each pair, out[3*p+0] = number of pixels with sqrt(u*u+v*v) >= thresh,
+ * out[3*p+1] = sum of their column indices, out[3*p+2] = sum of their row indices (fp64, exact
+ * integers), so that only 3 scalars per pair leave the GPU instead of two planes.
+ */
+int lkflow_flow_centroid_f64_dev(lkflow_ctx *ctx, const double *U, const double *V,
+                                 size_t uv_pair_stride_bytes, int n_pairs, int rows, int cols,
+                                 size_t uv_step_bytes, double thresh, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LKFLOW_H */

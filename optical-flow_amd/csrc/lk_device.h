@@ -1,0 +1,168 @@
+// lk_device.h -- per-pixel device primitives shared by every kernel (gfx950, fp64).
+//
+// Each function restates one row of SURVEY.md 8(a); expression ORDER mirrors the OpenCV 2.4
+// templates the reference calls, and the translation unit is compiled with -ffp-contract=off so
+// that no product is fused into an FMA (the reference rounds every product).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+namespace lk {
+
+// A batch of strided fp64 planes: element (p, y, x) lives at base[p*plane + y*pitch + x].
+struct Planes {
+    double *base;
+    long long plane;  // elements between planes
+    long long pitch;  // elements between rows
+    __device__ __forceinline__ double *at(int p) const { return base + (long long)p * plane; }
+};
+struct CPlanes {
+    const double *base;
+    long long plane;
+    long long pitch;
+    __device__ __forceinline__ const double *at(int p) const { return base + (long long)p * plane; }
+};
+
+// cv::borderInterpolate(p, len, BORDER_REFLECT_101)
+__device__ __forceinline__ int r101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// The three 2x2 filter2D responses of ONE image (anchor (1,1)): p00=I(y-1,x-1) p01=I(y-1,x)
+// p10=I(y,x-1) p11=I(y,x).  ParallelVideoPyr.cpp:44-84; accumulation order of OpenCV 2.4
+// Filter2D (s = 0; s += k*tap in row-major tap order).
+__device__ __forceinline__ double f2d_x(double p00, double p01, double p10, double p11)
+{
+    return ((-p00 + p01) - p10) + p11;  // [[-1, 1], [-1, 1]]
+}
+__device__ __forceinline__ double f2d_y(double p00, double p01, double p10, double p11)
+{
+    return ((-p00 - p01) + p10) + p11;  // [[-1,-1], [ 1, 1]]
+}
+__device__ __forceinline__ double f2d_neg(double p00, double p01, double p10, double p11)
+{
+    return ((-p00 - p01) - p10) - p11;  // all -1 (image 1 of get_ft)
+}
+__device__ __forceinline__ double f2d_pos(double p00, double p01, double p10, double p11)
+{
+    return ((p00 + p01) + p10) + p11;  // all +1 (image 2 of get_ft)
+}
+
+// fx, fy, ft and the five products fx2, fy2, fxfy, fxft, fyft (ParallelVideoPyr.cpp:378-405).
+// a** = image 1 taps, b** = image 2 taps.
+__device__ __forceinline__ void lk_products(double a00, double a01, double a10, double a11,
+                                            double b00, double b01, double b10, double b11,
+                                            double p[5])
+{
+    const double fx = f2d_x(a00, a01, a10, a11) + f2d_x(b00, b01, b10, b11);
+    const double fy = f2d_y(a00, a01, a10, a11) + f2d_y(b00, b01, b10, b11);
+    const double ft = f2d_neg(a00, a01, a10, a11) + f2d_pos(b00, b01, b10, b11);
+    p[0] = fx * fx;
+    p[1] = fy * fy;
+    p[2] = fx * fy;
+    p[3] = fx * ft;
+    p[4] = fy * ft;
+}
+
+// Products at (y,x) straight from global memory (used for the clipped-window rule and by the
+// naive kernel).  Reflect-101 on the -1 row/column.
+__device__ __forceinline__ void lk_products_at(const double *I1, const double *I2, long long pitch,
+                                               int H, int W, int y, int x, double p[5])
+{
+    const int ym = r101(y - 1, H), xm = r101(x - 1, W);
+    const double *r0a = I1 + (long long)ym * pitch, *r1a = I1 + (long long)y * pitch;
+    const double *r0b = I2 + (long long)ym * pitch, *r1b = I2 + (long long)y * pitch;
+    lk_products(r0a[xm], r0a[x], r1a[xm], r1a[x], r0b[xm], r0b[x], r1b[xm], r1b[x], p);
+}
+
+// 2x2 solve + OpenCV-2.4 divide (den == 0 -> 0).  ParallelVideoPyr.cpp:470-472, 510-520.
+// s = {Sxx, Syy, Sxy, Sxt, Syt}
+__device__ __forceinline__ void lk_solve(const double s[5], double &u, double &v)
+{
+    const double det = s[0] * s[1] - s[2] * s[2];
+    const double un = s[2] * s[4] - s[1] * s[3];
+    const double vn = s[3] * s[2] - s[0] * s[4];
+    u = det != 0.0 ? un / det : 0.0;
+    v = det != 0.0 ? vn / det : 0.0;
+}
+
+// Horizontal pass of cv::pyrUp at fine column x for one coarse row c[0..Wc) (OpenCV 2.4
+// pyramids.cpp pyrUp_; asymmetric borders exactly as the template writes them).
+__device__ __forceinline__ double pyrup_h(const double *c, int Wc, int x)
+{
+    const int j = x >> 1;
+    if (Wc == 1) return c[0] * 8;
+    if ((x & 1) == 0) {
+        if (j == 0) return c[0] * 6 + c[1] * 2;
+        if (j == Wc - 1) return c[Wc - 2] + c[Wc - 1] * 7;
+        return c[j - 1] + c[j] * 6 + c[j + 1];
+    }
+    if (j == Wc - 1) return c[Wc - 1] * 8;
+    return (c[j] + c[j + 1]) * 4;
+}
+
+// cv::pyrUp value at fine pixel (y,x) of a coarse Hc x Wc plane (ParallelVideoPyr.cpp:646-647).
+__device__ __forceinline__ double pyrup_at(const double *c, long long pitch, int Hc, int Wc, int y,
+                                           int x)
+{
+    const int i = y >> 1;
+    const int s1 = r101(2 * i, 2 * Hc) >> 1;
+    const int s2 = r101(2 * (i + 1), 2 * Hc) >> 1;
+    const double r1 = pyrup_h(c + (long long)s1 * pitch, Wc, x);
+    const double r2 = pyrup_h(c + (long long)s2 * pitch, Wc, x);
+    if (y & 1) return ((r1 + r2) * 4) * (1.0 / 64);
+    const int s0 = r101(2 * (i - 1), 2 * Hc) >> 1;
+    const double r0 = pyrup_h(c + (long long)s0 * pitch, Wc, x);
+    return (r0 + r1 * 6 + r2) * (1.0 / 64);
+}
+
+// cvRound as OpenCV 2.4 compiles it on x86-64 (cvtsd2si): round-half-even; NaN / out of range ->
+// 0x80000000.
+__device__ __forceinline__ int cv_round(double v)
+{
+    if (!(v > -2147483648.5 && v < 2147483647.5)) return INT_MIN;
+    return __double2int_rn(v);
+}
+
+__device__ __forceinline__ int sat_short(int v)
+{
+    return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+}
+
+// cv::remap INTER_LINEAR / BORDER_CONSTANT(0) sample of src at float map coordinate (mx,my)
+// (OpenCV 2.4 imgwarp.cpp: 1/32-pixel fixed point, float weight table, fp64 blend).
+__device__ __forceinline__ double remap_bilinear(const double *src, long long pitch, int H, int W,
+                                                 float mx, float my)
+{
+    const int sx = cv_round((double)(mx * 32.0f));
+    const int sy = cv_round((double)(my * 32.0f));
+    const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
+    const float a = (float)(sx & 31) * (1.0f / 32), b = (float)(sy & 31) * (1.0f / 32);
+    const float w0 = (1.0f - b) * (1.0f - a), w1 = (1.0f - b) * a, w2 = b * (1.0f - a), w3 = b * a;
+    const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W;
+    const bool y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
+    const double *r0 = src + (long long)iy * pitch + ix;
+    const double *r1 = r0 + pitch;
+    const double v0 = (y0 && x0) ? r0[0] : 0.0;
+    const double v1 = (y0 && x1) ? r0[1] : 0.0;
+    const double v2 = (y1 && x0) ? r1[0] : 0.0;
+    const double v3 = (y1 && x1) ? r1[1] : 0.0;
+    return v0 * (double)w0 + v1 * (double)w1 + v2 * (double)w2 + v3 * (double)w3;
+}
+
+// Map build (ParallelVideoPyr.cpp:674-678) + remap of both images at fine pixel (y,x):
+// image 1 sampled at (x + f.x/2, y + f.y/2), image 2 at (x - f.x/2, y - f.y/2); float32 map math.
+__device__ __forceinline__ void warp_pair_at(const double *I1, const double *I2, long long pitch,
+                                             int H, int W, int y, int x, double upu, double upv,
+                                             double &w1, double &w2)
+{
+    const float fx = (float)upu, fy = (float)upv;
+    const float hx = fx / 2, hy = fy / 2;
+    w1 = remap_bilinear(I1, pitch, H, W, (float)x + hx, (float)y + hy);
+    w2 = remap_bilinear(I2, pitch, H, W, (float)x - hx, (float)y - hy);
+}
+
+}  // namespace lk

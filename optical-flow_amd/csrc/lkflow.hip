@@ -1,0 +1,560 @@
+// lkflow.hip -- host side of liblkflow.so: context, workspace, launch sequencing, C ABI.
+//
+// The coarse-to-fine driver below is the device counterpart of coarseToFineEstimation
+// (ParallelVideoPyr.cpp:578-725 / SerialPyr.cpp:157-194):
+//     pyramids (a2) -> for l = L-1 .. 0 { [warp with up(flow_{l+1})] (a9-a12) ; LK + up (a3-a8) }
+// Everything is enqueued on ONE stream with no host synchronisation, so a caller may capture a
+// call into a HIP graph after lkflow_ctx_reserve().
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lkflow.h"
+#include "lk_kernels.h"
+
+#define LKFLOW_VERSION_STR "lkflow-mi355x 0.1 (gfx950)"
+
+namespace {
+
+using lk::CPlanes;
+using lk::Planes;
+
+inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
+
+struct Level {
+    int H, W;
+    long long pitch;  // elements
+    long long plane;  // elements (pitch * H, padded)
+};
+
+}  // namespace
+
+struct lkflow_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    std::string last_error;
+    // options
+    int impl = 0;
+    int tile_rows = 0;
+    // workspace arena
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    // geometry the arena was carved for
+    int g_rows = 0, g_cols = 0, g_levels = 0, g_pairs = 0;
+    std::vector<Level> lv;
+    // arena offsets (in elements) per level; planes of frame 1 then frame 2: [2*pairs] planes
+    std::vector<long long> off_pyr;   // level >= 1
+    std::vector<long long> off_warp;  // level <= L-2
+    std::vector<long long> off_flow;  // level >= 1: u planes [pairs] then v planes [pairs]
+    // host-API staging (prev, next, U, V contiguous planes)
+    double *stage = nullptr;
+    size_t stage_bytes = 0;
+};
+
+namespace {
+
+bool hip_ok(lkflow_ctx *ctx, hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    if (ctx) ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define HIP_TRY(ctx, call)                                   \
+    do {                                                     \
+        if (!hip_ok((ctx), (call), #call)) return LKFLOW_E_HIP; \
+    } while (0)
+
+int max_levels(int cols, int rows)
+{
+    if (cols <= 0 || rows <= 0) return 0;
+    int p = 1;
+    while (cols % (1 << p) == 0) ++p;
+    int res = p;
+    p = 1;
+    while (rows % (1 << p) == 0) ++p;
+    return res < p ? res : p;
+}
+
+int check_common(int rows, int cols, size_t step_bytes, size_t uv_step_bytes, int n_pairs)
+{
+    if (rows < 1 || cols < 1 || n_pairs < 1 || n_pairs > 32767) return LKFLOW_E_ARG;
+    if (step_bytes < (size_t)cols * 8 || step_bytes % 8) return LKFLOW_E_ARG;
+    if (uv_step_bytes < (size_t)cols * 8 || uv_step_bytes % 8) return LKFLOW_E_ARG;
+    return LKFLOW_OK;
+}
+
+int check_win(int win)
+{
+    if (win < 3 || (win & 1) == 0 || win > LKFLOW_MAX_WIN) return LKFLOW_E_WIN;
+    return LKFLOW_OK;
+}
+
+// Carve (or re-carve) the arena for a (rows, cols, levels, pairs) problem.
+int ensure_workspace(lkflow_ctx *ctx, int rows, int cols, int levels, int pairs)
+{
+    if (ctx->g_rows == rows && ctx->g_cols == cols && ctx->g_levels == levels &&
+        ctx->g_pairs >= pairs && ctx->arena)
+        return LKFLOW_OK;
+    std::vector<Level> lv(levels);
+    lv[0] = {rows, cols, align_up(cols, 16), 0};
+    for (int l = 1; l < levels; ++l)
+        lv[l] = {(lv[l - 1].H + 1) / 2, (lv[l - 1].W + 1) / 2, 0, 0};
+    for (int l = 0; l < levels; ++l) {
+        lv[l].pitch = align_up(lv[l].W, 16);
+        lv[l].plane = align_up(lv[l].pitch * lv[l].H, 32);
+    }
+    std::vector<long long> off_pyr(levels, -1), off_warp(levels, -1), off_flow(levels, -1);
+    long long cur = 0;
+    for (int l = 1; l < levels; ++l) { off_pyr[l] = cur; cur += 2LL * pairs * lv[l].plane; }
+    for (int l = 0; l + 1 < levels; ++l) { off_warp[l] = cur; cur += 2LL * pairs * lv[l].plane; }
+    for (int l = 1; l < levels; ++l) { off_flow[l] = cur; cur += 2LL * pairs * lv[l].plane; }
+    size_t need = (size_t)cur * sizeof(double) + 256;
+    if (need > ctx->arena_bytes) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        if (ctx->arena) { HIP_TRY(ctx, hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_bytes = 0; }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) {
+            hip_ok(ctx, e, "hipMalloc(workspace)");
+            return LKFLOW_E_NOMEM;
+        }
+        ctx->arena = (char *)p;
+        ctx->arena_bytes = need;
+    }
+    ctx->lv = lv;
+    ctx->off_pyr = off_pyr;
+    ctx->off_warp = off_warp;
+    ctx->off_flow = off_flow;
+    ctx->g_rows = rows; ctx->g_cols = cols; ctx->g_levels = levels; ctx->g_pairs = pairs;
+    return LKFLOW_OK;
+}
+
+inline double *arena_at(lkflow_ctx *ctx, long long off_elems)
+{
+    return reinterpret_cast<double *>(ctx->arena) + off_elems;
+}
+
+inline dim3 grid_px(int W, int H, int planes) { return dim3((W + 63) / 64, (H + 3) / 4, planes); }
+
+// ---- LK launch ---------------------------------------------------------------------------------
+constexpr int LK_TX = 256;
+
+template <int WIN>
+void launch_lk_win(const lk::LKArgs &a, bool has_up, dim3 grid, hipStream_t s)
+{
+    if (has_up)
+        hipLaunchKernelGGL((lk::lk_march_kernel<WIN, LK_TX, true>), grid, dim3(LK_TX), 0, s, a);
+    else
+        hipLaunchKernelGGL((lk::lk_march_kernel<WIN, LK_TX, false>), grid, dim3(LK_TX), 0, s, a);
+}
+
+int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hipStream_t s)
+{
+    if (ctx->impl == 1) {
+        dim3 g = grid_px(a.W, a.H, pairs);
+        if (has_up) hipLaunchKernelGGL((lk::lk_naive_kernel<true>), g, dim3(256), 0, s, a, win);
+        else hipLaunchKernelGGL((lk::lk_naive_kernel<false>), g, dim3(256), 0, s, a, win);
+        HIP_TRY(ctx, hipGetLastError());
+        return LKFLOW_OK;
+    }
+    const int R = win / 2;
+    const int xo = LK_TX - 2 * R - 1;
+    const int gx = (a.W + xo - 1) / xo;
+    int th = ctx->tile_rows;
+    if (th <= 0) {
+        th = 128;
+        while (th > 16 && (long long)gx * ((a.H + th - 1) / th) * pairs < 2048) th >>= 1;
+    }
+    if (th > a.H) th = a.H;
+    a.th = th;
+    dim3 grid(gx, (a.H + th - 1) / th, pairs);
+    switch (win) {
+#define LK_CASE(WN) case WN: launch_lk_win<WN>(a, has_up, grid, s); break;
+        LK_CASE(3) LK_CASE(5) LK_CASE(7) LK_CASE(9) LK_CASE(11) LK_CASE(13) LK_CASE(15) LK_CASE(17)
+        LK_CASE(19) LK_CASE(21) LK_CASE(23) LK_CASE(25) LK_CASE(27) LK_CASE(29) LK_CASE(31)
+#undef LK_CASE
+        default: return LKFLOW_E_WIN;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
+int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int planes, hipStream_t s)
+{
+    const int Hd = (H + 1) / 2, Wd = (W + 1) / 2;
+    hipLaunchKernelGGL(lk::pyrdown_kernel, grid_px(Wd, Hd, planes), dim3(256), 0, s, src, H, W, dst,
+                       Hd, Wd);
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
+int launch_warp(lkflow_ctx *ctx, CPlanes i1, CPlanes i2, int H, int W, CPlanes cu, CPlanes cv,
+                Planes o1, Planes o2, int pairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(lk::warp_kernel, grid_px(W, H, pairs), dim3(256), 0, s, i1, i2, H, W, cu, cv,
+                       o1, o2);
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
+int set_device(lkflow_ctx *ctx)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return LKFLOW_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int lkflow_max_levels(int cols, int rows) { return max_levels(cols, rows); }
+
+const char *lkflow_strerror(int status)
+{
+    switch (status) {
+        case LKFLOW_OK: return "ok";
+        case LKFLOW_E_ARG: return "invalid argument (null pointer, size, step or flags)";
+        case LKFLOW_E_LEVELS: return "pyr_levels out of range [1, lkflow_max_levels(cols, rows)]";
+        case LKFLOW_E_WIN: return "win must be odd, >= 3 and <= LKFLOW_MAX_WIN";
+        case LKFLOW_E_HIP: return "HIP runtime error";
+        case LKFLOW_E_NOMEM: return "device workspace allocation failed";
+        case LKFLOW_E_NODEVICE: return "no usable HIP device";
+        default: return "unknown lkflow status";
+    }
+}
+
+const char *lkflow_last_error(const lkflow_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char *lkflow_version(void) { return LKFLOW_VERSION_STR; }
+
+int lkflow_ctx_create(lkflow_ctx **out, int device)
+{
+    if (!out) return LKFLOW_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+        return LKFLOW_E_NODEVICE;
+    lkflow_ctx *ctx = new (std::nothrow) lkflow_ctx();
+    if (!ctx) return LKFLOW_E_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return LKFLOW_E_HIP;
+    }
+    *out = ctx;
+    return LKFLOW_OK;
+}
+
+void lkflow_ctx_destroy(lkflow_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value)
+{
+    if (!ctx) return LKFLOW_E_ARG;
+    switch (key) {
+        case LKFLOW_OPT_IMPL:
+            if (value < 0 || value > 1) return LKFLOW_E_ARG;
+            ctx->impl = value;
+            return LKFLOW_OK;
+        case LKFLOW_OPT_TILE_ROWS:
+            if (value < 0 || value > 4096) return LKFLOW_E_ARG;
+            ctx->tile_rows = value;
+            return LKFLOW_OK;
+        default: return LKFLOW_E_ARG;
+    }
+}
+
+size_t lkflow_ctx_workspace_bytes(const lkflow_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
+
+int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int n_pairs)
+{
+    if (!ctx || rows < 1 || cols < 1 || n_pairs < 1 || n_pairs > 32767) return LKFLOW_E_ARG;
+    if (pyr_levels < 1 || pyr_levels > max_levels(cols, rows)) return LKFLOW_E_LEVELS;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    return ensure_workspace(ctx, rows, cols, pyr_levels, n_pairs);
+}
+
+// ---- single-level LK ---------------------------------------------------------------------------
+int lkflow_lk_batch_f64_dev(lkflow_ctx *ctx, const double *img1, const double *img2,
+                            size_t s1, size_t s2, int n_pairs, int rows, int cols, size_t step_bytes,
+                            double *U, double *V, size_t uv_pair_stride_bytes, size_t uv_step_bytes,
+                            int win, void *stream)
+{
+    if (!ctx || !img1 || !img2 || !U || !V) return LKFLOW_E_ARG;
+    int rc = check_common(rows, cols, step_bytes, uv_step_bytes, n_pairs);
+    if (rc) return rc;
+    if (s1 % 8 || s2 % 8 || uv_pair_stride_bytes % 8) return LKFLOW_E_ARG;
+    if ((rc = check_win(win))) return rc;
+    if ((rc = set_device(ctx))) return rc;
+    // both images must share one pair stride for the kernel's plane addressing
+    lk::LKArgs a{};
+    a.i1 = {img1, (long long)(s1 / 8), (long long)(step_bytes / 8)};
+    a.i2 = {img2, (long long)(s2 / 8), (long long)(step_bytes / 8)};
+    a.u = {U, (long long)(uv_pair_stride_bytes / 8), (long long)(uv_step_bytes / 8)};
+    a.v = {V, (long long)(uv_pair_stride_bytes / 8), (long long)(uv_step_bytes / 8)};
+    a.H = rows; a.W = cols;
+    return launch_lk(ctx, a, false, n_pairs, win, (hipStream_t)stream);
+}
+
+// ---- full pyramid ------------------------------------------------------------------------------
+int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, size_t prev_ps,
+                                 size_t next_ps, int n_pairs, int rows, int cols, size_t step_bytes,
+                                 double *U, double *V, size_t uv_ps, size_t uv_step_bytes,
+                                 int pyr_levels, int win, unsigned flags, void *stream)
+{
+    if (!ctx || !prev || !next || !U || !V) return LKFLOW_E_ARG;
+    int rc = check_common(rows, cols, step_bytes, uv_step_bytes, n_pairs);
+    if (rc) return rc;
+    if (prev_ps % 8 || next_ps % 8 || uv_ps % 8) return LKFLOW_E_ARG;
+    if (flags & ~LKFLOW_MUTATE_INPUTS) return LKFLOW_E_ARG;
+    if ((flags & LKFLOW_MUTATE_INPUTS) && n_pairs != 1) return LKFLOW_E_ARG;
+    if (pyr_levels < 1 || pyr_levels > max_levels(cols, rows)) return LKFLOW_E_LEVELS;
+    if ((rc = check_win(win))) return rc;
+    if ((rc = set_device(ctx))) return rc;
+    if ((rc = ensure_workspace(ctx, rows, cols, pyr_levels, n_pairs))) return rc;
+
+    hipStream_t s = (hipStream_t)stream;
+    const int L = pyr_levels, P = n_pairs;
+    const std::vector<Level> &lv = ctx->lv;
+    const long long step = (long long)(step_bytes / 8);
+
+    // image planes of frame f (0 = prev, 1 = next) at level l, original (un-warped)
+    auto pyr = [&](int l, int f) -> CPlanes {
+        if (l == 0) return f == 0 ? CPlanes{prev, (long long)(prev_ps / 8), step}
+                                  : CPlanes{next, (long long)(next_ps / 8), step};
+        return CPlanes{arena_at(ctx, ctx->off_pyr[l] + (long long)f * P * lv[l].plane), lv[l].plane,
+                       lv[l].pitch};
+    };
+    auto pyr_w = [&](int l, int f) -> Planes {
+        return Planes{arena_at(ctx, ctx->off_pyr[l] + (long long)f * P * lv[l].plane), lv[l].plane,
+                      lv[l].pitch};
+    };
+    auto warp_w = [&](int l, int f) -> Planes {
+        return Planes{arena_at(ctx, ctx->off_warp[l] + (long long)f * P * lv[l].plane), lv[l].plane,
+                      lv[l].pitch};
+    };
+    auto flow_w = [&](int l, int c) -> Planes {  // c: 0 = u, 1 = v
+        if (l == 0) return c == 0 ? Planes{U, (long long)(uv_ps / 8), (long long)(uv_step_bytes / 8)}
+                                  : Planes{V, (long long)(uv_ps / 8), (long long)(uv_step_bytes / 8)};
+        return Planes{arena_at(ctx, ctx->off_flow[l] + (long long)c * P * lv[l].plane), lv[l].plane,
+                      lv[l].pitch};
+    };
+    auto as_c = [](Planes p) { return CPlanes{p.base, p.plane, p.pitch}; };
+
+    // a2: Gaussian pyramids of both frames (built from the ORIGINAL images, before any warp)
+    for (int l = 1; l < L; ++l) {
+        if (l == 1) {
+            for (int f = 0; f < 2; ++f)
+                if ((rc = launch_pyrdown(ctx, pyr(0, f), lv[0].H, lv[0].W, pyr_w(1, f), P, s))) return rc;
+        } else {
+            // frames 1 and 2 are adjacent in the arena: one launch over 2P planes
+            if ((rc = launch_pyrdown(ctx, pyr(l - 1, 0), lv[l - 1].H, lv[l - 1].W, pyr_w(l, 0), 2 * P, s)))
+                return rc;
+        }
+    }
+
+    // a13: coarse-to-fine loop
+    for (int l = L - 1; l >= 0; --l) {
+        lk::LKArgs a{};
+        a.H = lv[l].H; a.W = lv[l].W;
+        a.u = flow_w(l, 0); a.v = flow_w(l, 1);
+        const bool has_up = l != L - 1;
+        if (has_up) {
+            CPlanes cu = as_c(flow_w(l + 1, 0)), cv = as_c(flow_w(l + 1, 1));
+            // a9-a12: warp level l with the up-sampled flow of level l+1
+            if ((rc = launch_warp(ctx, pyr(l, 0), pyr(l, 1), lv[l].H, lv[l].W, cu, cv, warp_w(l, 0),
+                                  warp_w(l, 1), P, s)))
+                return rc;
+            a.i1 = as_c(warp_w(l, 0)); a.i2 = as_c(warp_w(l, 1));
+            a.cu = cu; a.cv = cv;
+        } else {
+            a.i1 = pyr(l, 0); a.i2 = pyr(l, 1);
+        }
+        if ((rc = launch_lk(ctx, a, has_up, P, win, s))) return rc;
+    }
+
+    // a12 at level 0: the reference's pyr[0] IS the caller's buffer, so its warp lands there
+    if ((flags & LKFLOW_MUTATE_INPUTS) && L >= 2) {
+        Planes w1 = warp_w(0, 0), w2 = warp_w(0, 1);
+        HIP_TRY(ctx, hipMemcpy2DAsync(prev, step_bytes, w1.base, (size_t)w1.pitch * 8, (size_t)cols * 8,
+                                      rows, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(ctx, hipMemcpy2DAsync(next, step_bytes, w2.base, (size_t)w2.pitch * 8, (size_t)cols * 8,
+                                      rows, hipMemcpyDeviceToDevice, s));
+    }
+    return LKFLOW_OK;
+}
+
+// ---- host-buffer drop-ins ----------------------------------------------------------------------
+static int ensure_stage(lkflow_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->stage_bytes) return LKFLOW_OK;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (ctx->stage) { HIP_TRY(ctx, hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { hip_ok(ctx, e, "hipMalloc(stage)"); return LKFLOW_E_NOMEM; }
+    ctx->stage = (double *)p;
+    ctx->stage_bytes = bytes;
+    return LKFLOW_OK;
+}
+
+int lkflow_compute_f64(lkflow_ctx *ctx, double *prev, double *next, int rows, int cols,
+                       size_t step_bytes, double *U, double *V, size_t uv_step_bytes, int pyr_levels,
+                       int win, unsigned flags)
+{
+    if (!ctx || !prev || !next || !U || !V) return LKFLOW_E_ARG;
+    int rc = check_common(rows, cols, step_bytes, uv_step_bytes, 1);
+    if (rc) return rc;
+    if (flags & ~LKFLOW_MUTATE_INPUTS) return LKFLOW_E_ARG;
+    if (pyr_levels < 1 || pyr_levels > max_levels(cols, rows)) return LKFLOW_E_LEVELS;
+    if ((rc = check_win(win))) return rc;
+    if ((rc = set_device(ctx))) return rc;
+    const size_t row_b = (size_t)cols * 8, plane_b = row_b * rows;
+    if ((rc = ensure_stage(ctx, 4 * plane_b))) return rc;
+    double *d_prev = ctx->stage, *d_next = d_prev + (size_t)rows * cols, *d_u = d_next + (size_t)rows * cols,
+           *d_v = d_u + (size_t)rows * cols;
+    hipStream_t s = ctx->own_stream;
+    HIP_TRY(ctx, hipMemcpy2DAsync(d_prev, row_b, prev, step_bytes, row_b, rows, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpy2DAsync(d_next, row_b, next, step_bytes, row_b, rows, hipMemcpyHostToDevice, s));
+    rc = lkflow_compute_batch_f64_dev(ctx, d_prev, d_next, plane_b, plane_b, 1, rows, cols, row_b, d_u, d_v,
+                                      plane_b, row_b, pyr_levels, win, flags, s);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy2DAsync(U, uv_step_bytes, d_u, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpy2DAsync(V, uv_step_bytes, d_v, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
+    if ((flags & LKFLOW_MUTATE_INPUTS) && pyr_levels >= 2) {
+        HIP_TRY(ctx, hipMemcpy2DAsync(prev, step_bytes, d_prev, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpy2DAsync(next, step_bytes, d_next, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return LKFLOW_OK;
+}
+
+int lkflow_lk_f64(lkflow_ctx *ctx, const double *img1, const double *img2, int rows, int cols,
+                  size_t step_bytes, double *U, double *V, size_t uv_step_bytes, int win)
+{
+    if (!ctx || !img1 || !img2 || !U || !V) return LKFLOW_E_ARG;
+    int rc = check_common(rows, cols, step_bytes, uv_step_bytes, 1);
+    if (rc) return rc;
+    if ((rc = check_win(win))) return rc;
+    if ((rc = set_device(ctx))) return rc;
+    const size_t row_b = (size_t)cols * 8, plane_b = row_b * rows;
+    if ((rc = ensure_stage(ctx, 4 * plane_b))) return rc;
+    double *d_1 = ctx->stage, *d_2 = d_1 + (size_t)rows * cols, *d_u = d_2 + (size_t)rows * cols,
+           *d_v = d_u + (size_t)rows * cols;
+    hipStream_t s = ctx->own_stream;
+    HIP_TRY(ctx, hipMemcpy2DAsync(d_1, row_b, img1, step_bytes, row_b, rows, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpy2DAsync(d_2, row_b, img2, step_bytes, row_b, rows, hipMemcpyHostToDevice, s));
+    rc = lkflow_lk_batch_f64_dev(ctx, d_1, d_2, plane_b, plane_b, 1, rows, cols, row_b, d_u, d_v, plane_b,
+                                 row_b, win, s);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy2DAsync(U, uv_step_bytes, d_u, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpy2DAsync(V, uv_step_bytes, d_v, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return LKFLOW_OK;
+}
+
+// ---- stage entry points ------------------------------------------------------------------------
+int lkflow_pyrdown_f64_dev(lkflow_ctx *ctx, const double *src, size_t src_ps, int n_planes, int rows,
+                           int cols, size_t src_step_bytes, double *dst, size_t dst_ps,
+                           size_t dst_step_bytes, void *stream)
+{
+    if (!ctx || !src || !dst || rows < 1 || cols < 1 || n_planes < 1 || n_planes > 65535) return LKFLOW_E_ARG;
+    if (src_step_bytes < (size_t)cols * 8 || src_step_bytes % 8 || src_ps % 8 || dst_ps % 8) return LKFLOW_E_ARG;
+    if (dst_step_bytes < (size_t)((cols + 1) / 2) * 8 || dst_step_bytes % 8) return LKFLOW_E_ARG;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    return launch_pyrdown(ctx, CPlanes{src, (long long)(src_ps / 8), (long long)(src_step_bytes / 8)}, rows,
+                          cols, Planes{dst, (long long)(dst_ps / 8), (long long)(dst_step_bytes / 8)},
+                          n_planes, (hipStream_t)stream);
+}
+
+int lkflow_pyrup_f64_dev(lkflow_ctx *ctx, const double *src, size_t src_ps, int n_planes, int rows,
+                         int cols, size_t src_step_bytes, double *dst, size_t dst_ps,
+                         size_t dst_step_bytes, void *stream)
+{
+    if (!ctx || !src || !dst || rows < 1 || cols < 1 || n_planes < 1 || n_planes > 65535) return LKFLOW_E_ARG;
+    if (src_step_bytes < (size_t)cols * 8 || src_step_bytes % 8 || src_ps % 8 || dst_ps % 8) return LKFLOW_E_ARG;
+    if (dst_step_bytes < (size_t)cols * 16 || dst_step_bytes % 8) return LKFLOW_E_ARG;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lk::pyrup_kernel, grid_px(2 * cols, 2 * rows, n_planes), dim3(256), 0,
+                       (hipStream_t)stream,
+                       CPlanes{src, (long long)(src_ps / 8), (long long)(src_step_bytes / 8)}, rows, cols,
+                       Planes{dst, (long long)(dst_ps / 8), (long long)(dst_step_bytes / 8)});
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
+int lkflow_warp_f64_dev(lkflow_ctx *ctx, const double *img1, const double *img2, size_t img_ps, int n_pairs,
+                        int rows, int cols, size_t img_step_bytes, const double *cu, const double *cv,
+                        size_t c_ps, size_t c_step_bytes, double *out1, double *out2, size_t out_ps,
+                        size_t out_step_bytes, void *stream)
+{
+    if (!ctx || !img1 || !img2 || !cu || !cv || !out1 || !out2) return LKFLOW_E_ARG;
+    if (rows < 2 || cols < 2 || (rows & 1) || (cols & 1) || n_pairs < 1 || n_pairs > 65535) return LKFLOW_E_ARG;
+    if (img_step_bytes < (size_t)cols * 8 || out_step_bytes < (size_t)cols * 8 ||
+        c_step_bytes < (size_t)(cols / 2) * 8)
+        return LKFLOW_E_ARG;
+    if (img_step_bytes % 8 || out_step_bytes % 8 || c_step_bytes % 8 || img_ps % 8 || c_ps % 8 || out_ps % 8)
+        return LKFLOW_E_ARG;
+    if (out1 == img1 || out2 == img2 || out1 == img2 || out2 == img1) return LKFLOW_E_ARG;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    const long long ip = img_ps / 8, is = img_step_bytes / 8, cp = c_ps / 8, cs = c_step_bytes / 8,
+                    op = out_ps / 8, os = out_step_bytes / 8;
+    return launch_warp(ctx, CPlanes{img1, ip, is}, CPlanes{img2, ip, is}, rows, cols, CPlanes{cu, cp, cs},
+                       CPlanes{cv, cp, cs}, Planes{out1, op, os}, Planes{out2, op, os}, n_pairs,
+                       (hipStream_t)stream);
+}
+
+int lkflow_u8_to_f64_dev(lkflow_ctx *ctx, const unsigned char *src, double *dst, size_t n, void *stream)
+{
+    if (!ctx || !src || !dst) return LKFLOW_E_ARG;
+    if (n == 0) return LKFLOW_OK;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(lk::u8_to_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
+int lkflow_flow_centroid_f64_dev(lkflow_ctx *ctx, const double *U, const double *V, size_t uv_ps, int n_pairs,
+                                 int rows, int cols, size_t uv_step_bytes, double thresh, double *out,
+                                 void *stream)
+{
+    if (!ctx || !U || !V || !out || rows < 1 || cols < 1 || n_pairs < 1 || n_pairs > 65535) return LKFLOW_E_ARG;
+    if (uv_step_bytes < (size_t)cols * 8 || uv_step_bytes % 8 || uv_ps % 8) return LKFLOW_E_ARG;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(ctx, hipMemsetAsync(out, 0, (size_t)n_pairs * 3 * sizeof(double), s));
+    const long long ps = uv_ps / 8, st = uv_step_bytes / 8;
+    int gx = (cols + 255) / 256;
+    int gy = rows < 64 ? rows : 64;
+    hipLaunchKernelGGL(lk::centroid_kernel, dim3(gx, gy, n_pairs), dim3(256), 0, s, CPlanes{U, ps, st},
+                       CPlanes{V, ps, st}, rows, cols, thresh, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
+}  // extern "C"

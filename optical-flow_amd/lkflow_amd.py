@@ -1,0 +1,335 @@
+"""lkflow_amd -- Python host mirror of the reference's hot-call interface, over the C ABI.
+
+The product is liblkflow.so (HIP, gfx950); this module is a thin ctypes binding used by the parity
+tests, bench.py and the multi-GPU frame-pair sharding.  It mirrors the reference's own names:
+
+    getMaxLayer(img)                                   ParallelVideoPyr.cpp:545
+    getLucasKanadeOpticalFlow(img1, img2) -> (u, v)    ParallelVideoPyr.cpp:327
+    coarseToFineEstimation(img1, img2, nLevels)        ParallelVideoPyr.cpp:578
+    computeFlow(frame_prev, frame_next, pyr_levels, win)   (BASELINE.json's name for the same call)
+
+torch is used only as plumbing: device memory (tensor.data_ptr()) and the current HIP stream.
+There is NO CPU fallback: if liblkflow.so or a GPU is missing, calls raise.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblkflow.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lkflow.h")
+
+LKFLOW_OK = 0
+LKFLOW_E_ARG = -1
+LKFLOW_E_LEVELS = -2
+LKFLOW_E_WIN = -3
+LKFLOW_E_HIP = -4
+LKFLOW_E_NOMEM = -5
+LKFLOW_E_NODEVICE = -6
+LKFLOW_MUTATE_INPUTS = 1
+LKFLOW_MAX_WIN = 31
+LKFLOW_OPT_IMPL = 1
+LKFLOW_OPT_TILE_ROWS = 2
+
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_i = ctypes.c_int
+_u = ctypes.c_uint
+_d = ctypes.c_double
+
+# name -> (restype, argtypes); must list EVERY function declared in include/lkflow.h
+SIGNATURES = {
+    "lkflow_max_levels": (_i, [_i, _i]),
+    "lkflow_strerror": (ctypes.c_char_p, [_i]),
+    "lkflow_last_error": (ctypes.c_char_p, [_vp]),
+    "lkflow_version": (ctypes.c_char_p, []),
+    "lkflow_ctx_create": (_i, [ctypes.POINTER(_vp), _i]),
+    "lkflow_ctx_destroy": (None, [_vp]),
+    "lkflow_ctx_reserve": (_i, [_vp, _i, _i, _i, _i]),
+    "lkflow_ctx_set_option": (_i, [_vp, _i, _i]),
+    "lkflow_ctx_workspace_bytes": (_sz, [_vp]),
+    "lkflow_compute_f64": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp, _vp, _sz, _i, _i, _u]),
+    "lkflow_lk_f64": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp, _vp, _sz, _i]),
+    "lkflow_compute_batch_f64_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _i, _i, _sz, _vp, _vp, _sz,
+                                          _sz, _i, _i, _u, _vp]),
+    "lkflow_lk_batch_f64_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _i, _i, _sz, _vp, _vp, _sz, _sz, _i,
+                                     _vp]),
+    "lkflow_pyrdown_f64_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _vp, _sz, _sz, _vp]),
+    "lkflow_pyrup_f64_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _vp, _sz, _sz, _vp]),
+    "lkflow_warp_f64_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _vp, _vp, _sz, _sz, _vp, _vp,
+                                 _sz, _sz, _vp]),
+    "lkflow_u8_to_f64_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "lkflow_flow_centroid_f64_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _vp, _vp]),
+}
+
+_LIB = None
+
+
+class LKFlowError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = f"lkflow status {status}"
+        try:
+            msg += ": " + lib().lkflow_strerror(status).decode()
+        except Exception:
+            pass
+        if detail:
+            msg += f" [{detail}]"
+        super().__init__(msg)
+
+
+def header_functions():
+    """Names of all functions declared in include/lkflow.h (for the ABI-completeness test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lkflow_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load liblkflow.so (raises if it has not been built -- there is no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950); lkflow has no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def getMaxLayer(img_or_cols, rows=None):
+    """getMaxLayer (ParallelVideoPyr.cpp:545-564).  Accepts an image (H x W) or (cols, rows)."""
+    if rows is None:
+        h, w = img_or_cols.shape[-2:]
+        return lib().lkflow_max_levels(int(w), int(h))
+    return lib().lkflow_max_levels(int(img_or_cols), int(rows))
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr(stream=None):
+    torch = _torch()
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _check_dev(t, name):
+    torch = _torch()
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64):
+        raise TypeError(f"{name}: expected a float64 CUDA(HIP) tensor")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost stride must be 1")
+
+
+class Context:
+    """One lkflow_ctx (device workspace) on one GPU."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        rc = lib().lkflow_ctx_create(ctypes.byref(self._h), int(device))
+        if rc != 0:
+            self._h = None
+            raise LKFlowError(rc)
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().lkflow_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise LKFlowError(rc, lib().lkflow_last_error(self._h).decode())
+
+    def set_option(self, key, value):
+        self._chk(lib().lkflow_ctx_set_option(self._h, key, value))
+
+    def reserve(self, rows, cols, levels, n_pairs=1):
+        self._chk(lib().lkflow_ctx_reserve(self._h, rows, cols, levels, n_pairs))
+
+    @property
+    def workspace_bytes(self):
+        return lib().lkflow_ctx_workspace_bytes(self._h)
+
+    # ---- host (numpy) drop-ins --------------------------------------------------------------
+    def coarseToFineEstimation(self, img1, img2, nLevels, win=3, mutate=True):
+        """coarseToFineEstimation(img1, img2, u, v, nLevels) on host arrays; returns (u, v).
+        mutate=True reproduces the reference's in-place overwrite of img1/img2 (they must then be
+        writable float64 arrays with unit inner stride)."""
+        a, b = self._host_in(img1, mutate), self._host_in(img2, mutate)
+        h, w = a.shape
+        u, v = np.empty((h, w)), np.empty((h, w))
+        rc = lib().lkflow_compute_f64(self._h, a.ctypes.data, b.ctypes.data, h, w, a.strides[0],
+                                      u.ctypes.data, v.ctypes.data, u.strides[0], int(nLevels),
+                                      int(win), LKFLOW_MUTATE_INPUTS if mutate else 0)
+        self._chk(rc)
+        return u, v
+
+    def computeFlow(self, frame_prev, frame_next, pyr_levels, win=3):
+        """BASELINE.json's computeFlow(frame_prev, frame_next, U, V, pyr_levels, win): same call,
+        window generalised, inputs NOT mutated."""
+        return self.coarseToFineEstimation(frame_prev, frame_next, pyr_levels, win, mutate=False)
+
+    def getLucasKanadeOpticalFlow(self, img1, img2, win=3):
+        a, b = self._host_in(img1, False), self._host_in(img2, False)
+        h, w = a.shape
+        u, v = np.empty((h, w)), np.empty((h, w))
+        self._chk(lib().lkflow_lk_f64(self._h, a.ctypes.data, b.ctypes.data, h, w, a.strides[0],
+                                      u.ctypes.data, v.ctypes.data, u.strides[0], int(win)))
+        return u, v
+
+    @staticmethod
+    def _host_in(img, inplace):
+        if inplace:
+            if not (isinstance(img, np.ndarray) and img.dtype == np.float64 and img.ndim == 2 and
+                    img.strides[1] == 8 and img.flags.writeable):
+                raise TypeError("mutate=True needs writable 2-D float64 arrays with unit inner stride")
+            return img
+        a = np.asarray(img, dtype=np.float64)
+        if a.ndim != 2:
+            raise ValueError("expected a 2-D image")
+        if a.strides[1] != 8 or a.strides[0] < a.shape[1] * 8:
+            a = np.ascontiguousarray(a)
+        return a
+
+    # ---- device (torch) batched forms -------------------------------------------------------
+    def compute_batch(self, prev, nxt, levels, win=3, out=None, flags=0, stream=None):
+        """prev, nxt: [P, H, W] float64 CUDA tensors (any plane/row strides, unit inner stride).
+        Returns (U, V) [P, H, W].  Asynchronous on the current torch stream."""
+        torch = _torch()
+        _check_dev(prev, "prev"); _check_dev(nxt, "next")
+        if prev.dim() == 2:
+            prev, nxt = prev.unsqueeze(0), nxt.unsqueeze(0)
+        P, H, W = prev.shape
+        assert nxt.shape == prev.shape and nxt.stride(1) == prev.stride(1)
+        if out is None:
+            U = torch.empty((P, H, W), dtype=torch.float64, device=prev.device)
+            V = torch.empty((P, H, W), dtype=torch.float64, device=prev.device)
+        else:
+            U, V = out
+            _check_dev(U, "U"); _check_dev(V, "V")
+            assert U.shape == (P, H, W) and V.shape == (P, H, W)
+            assert U.stride() == V.stride()
+        rc = lib().lkflow_compute_batch_f64_dev(
+            self._h, prev.data_ptr(), nxt.data_ptr(), prev.stride(0) * 8, nxt.stride(0) * 8, P, H, W,
+            prev.stride(1) * 8, U.data_ptr(), V.data_ptr(), U.stride(0) * 8, U.stride(1) * 8,
+            int(levels), int(win), int(flags), _stream_ptr(stream))
+        self._chk(rc)
+        return U, V
+
+    def compute_video(self, frames, levels, win=3, out=None, stream=None):
+        """frames: [F, H, W] float64 CUDA tensor -> flow of the F-1 consecutive pairs."""
+        return self.compute_batch(frames[:-1], frames[1:], levels, win, out=out, stream=stream)
+
+    def lk_batch(self, img1, img2, win=3, stream=None):
+        torch = _torch()
+        _check_dev(img1, "img1"); _check_dev(img2, "img2")
+        if img1.dim() == 2:
+            img1, img2 = img1.unsqueeze(0), img2.unsqueeze(0)
+        P, H, W = img1.shape
+        assert img2.shape == img1.shape and img2.stride(1) == img1.stride(1)
+        U = torch.empty((P, H, W), dtype=torch.float64, device=img1.device)
+        V = torch.empty_like(U)
+        rc = lib().lkflow_lk_batch_f64_dev(
+            self._h, img1.data_ptr(), img2.data_ptr(), img1.stride(0) * 8, img2.stride(0) * 8, P, H, W,
+            img1.stride(1) * 8, U.data_ptr(), V.data_ptr(), U.stride(0) * 8, U.stride(1) * 8, int(win),
+            _stream_ptr(stream))
+        self._chk(rc)
+        return U, V
+
+    def pyrdown(self, src, stream=None):
+        torch = _torch()
+        _check_dev(src, "src")
+        if src.dim() == 2:
+            src = src.unsqueeze(0)
+        N, H, W = src.shape
+        dst = torch.empty((N, (H + 1) // 2, (W + 1) // 2), dtype=torch.float64, device=src.device)
+        self._chk(lib().lkflow_pyrdown_f64_dev(self._h, src.data_ptr(), src.stride(0) * 8, N, H, W,
+                                               src.stride(1) * 8, dst.data_ptr(), dst.stride(0) * 8,
+                                               dst.stride(1) * 8, _stream_ptr(stream)))
+        return dst
+
+    def pyrup(self, src, stream=None):
+        torch = _torch()
+        _check_dev(src, "src")
+        if src.dim() == 2:
+            src = src.unsqueeze(0)
+        N, H, W = src.shape
+        dst = torch.empty((N, 2 * H, 2 * W), dtype=torch.float64, device=src.device)
+        self._chk(lib().lkflow_pyrup_f64_dev(self._h, src.data_ptr(), src.stride(0) * 8, N, H, W,
+                                             src.stride(1) * 8, dst.data_ptr(), dst.stride(0) * 8,
+                                             dst.stride(1) * 8, _stream_ptr(stream)))
+        return dst
+
+    def warp(self, img1, img2, cu, cv, stream=None):
+        """img1,img2: [P,H,W]; cu,cv: [P,H/2,W/2] coarse flow -> warped (img1, img2)."""
+        torch = _torch()
+        for n, t in (("img1", img1), ("img2", img2), ("cu", cu), ("cv", cv)):
+            _check_dev(t, n)
+        P, H, W = img1.shape
+        assert img1.stride() == img2.stride() and cu.stride() == cv.stride()
+        o1, o2 = torch.empty_like(img1, memory_format=torch.contiguous_format), None
+        o2 = torch.empty_like(o1)
+        self._chk(lib().lkflow_warp_f64_dev(
+            self._h, img1.data_ptr(), img2.data_ptr(), img1.stride(0) * 8, P, H, W, img1.stride(1) * 8,
+            cu.data_ptr(), cv.data_ptr(), cu.stride(0) * 8, cu.stride(1) * 8, o1.data_ptr(),
+            o2.data_ptr(), o1.stride(0) * 8, o1.stride(1) * 8, _stream_ptr(stream)))
+        return o1, o2
+
+    def u8_to_f64(self, src, stream=None):
+        torch = _torch()
+        assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
+        dst = torch.empty(src.shape, dtype=torch.float64, device=src.device)
+        self._chk(lib().lkflow_u8_to_f64_dev(self._h, src.data_ptr(), dst.data_ptr(), src.numel(),
+                                             _stream_ptr(stream)))
+        return dst
+
+    def flow_centroid(self, U, V, thresh=20.0, stream=None):
+        """[P,H,W] flows -> [P,3] tensor (count, sum_x, sum_y) of pixels with |flow| >= thresh
+        (ParallelVideoPyr.cpp:845-873)."""
+        torch = _torch()
+        _check_dev(U, "U"); _check_dev(V, "V")
+        if U.dim() == 2:
+            U, V = U.unsqueeze(0), V.unsqueeze(0)
+        P, H, W = U.shape
+        assert U.stride() == V.stride()
+        out = torch.empty((P, 3), dtype=torch.float64, device=U.device)
+        self._chk(lib().lkflow_flow_centroid_f64_dev(self._h, U.data_ptr(), V.data_ptr(),
+                                                     U.stride(0) * 8, P, H, W, U.stride(1) * 8,
+                                                     float(thresh), out.data_ptr(),
+                                                     _stream_ptr(stream)))
+        return out
+
+
+# ---- frame-pair sharding of a video stream over ranks ---------------------------
+def shard_pairs(n_frames, world_size, rank):
+    """Contiguous block partition of the n_frames-1 consecutive pairs with a 1-frame overlap:
+    returns (first_frame, n_frames_local); rank r computes pairs [first, first + n_local - 1).
+    Blocks differ in size by at most one pair; trailing ranks may be empty (n_frames_local == 0)."""
+    n_pairs = max(n_frames - 1, 0)
+    base, rem = divmod(n_pairs, world_size)
+    cnt = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return (first, cnt + 1) if cnt > 0 else (first, 0)

@@ -1,0 +1,127 @@
+"""CPU suite: pins the oracle against the reference's own golden vectors.
+
+t1  U2Test/V2Test   single-level LK      (checker: parallelBasic.cpp:584-647)
+t2  UPyrTest/VPyrTest 7-level pyramid    (checker: ParallelBasicPyr.cpp:773-836, generator SerialPyr.cpp:247-249)
+t3  V2.txt          LK on the inputs mutated in place by the 7-level run (ctfLKof.cpp:246-254)
+Tolerance = the reference's own bar, abs 1e-6 (ParallelBasicPyr.cpp:787).
+"""
+import numpy as np
+import pytest
+
+TOL = 1e-6  # ParallelBasicPyr.cpp:787 "double thresh = 0.000001"
+
+
+def test_max_layer(oracle):
+    # SURVEY.md 8(a) a1
+    cases = {(640, 448): 7, (1080, 1080): 4, (1920, 1080): 4, (3840, 2160): 5, (7680, 4320): 6,
+             (240, 160): 5, (3264, 2448): 5, (1, 1): 1, (3, 5): 1, (2, 2): 2}
+    for (w, h), want in cases.items():
+        assert oracle.max_layer(w, h) == want
+
+
+def test_t1_single_level_golden(oracle, table_f64, goldens):
+    u, v = oracle.lucas_kanade(*table_f64, 3)
+    assert np.abs(u - goldens["U2Test"]).max() <= TOL
+    assert np.abs(v - goldens["V2Test"]).max() <= TOL
+    # invariants the goldens pin: zero border ring, no NaN/Inf
+    assert np.isfinite(u).all() and np.isfinite(v).all()
+    assert not u[0].any() and not u[-1].any() and not u[:, 0].any() and not u[:, -1].any()
+
+
+def test_t2_t3_pyramid_golden_and_inplace_warp(oracle, table_f64, goldens):
+    a, b = table_f64[0].copy(), table_f64[1].copy()
+    u, v = oracle.coarse_to_fine(a, b, oracle.max_layer(640, 448), 3, mutate=True)
+    assert np.abs(u - goldens["UPyrTest"]).max() <= TOL
+    assert np.abs(v - goldens["VPyrTest"]).max() <= TOL
+    # the reference's inputs were overwritten by the level-0 warp; V2.txt is LK on those
+    assert not np.array_equal(a, table_f64[0])
+    _, v2 = oracle.lucas_kanade(a, b, 3)
+    assert np.abs(v2 - goldens["V2"]).max() <= TOL
+
+
+def test_non_mutating_copy_gives_same_flow(oracle, table_f64, goldens):
+    u, v = oracle.coarse_to_fine(table_f64[0], table_f64[1], 7, 3, mutate=False)
+    assert np.abs(u - goldens["UPyrTest"]).max() <= TOL
+    assert np.abs(v - goldens["VPyrTest"]).max() <= TOL
+
+
+def test_level_and_window_validation(oracle, table_f64):
+    with pytest.raises(ValueError):
+        oracle.coarse_to_fine(*table_f64, 8, 3)      # > getMaxLayer: reference throws at :635
+    with pytest.raises(ValueError):
+        oracle.coarse_to_fine(*table_f64, 0, 3)
+    with pytest.raises(ValueError):
+        oracle.coarse_to_fine(*table_f64, 3, 4)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("levels,win", [(7, 3), (3, 15)])
+def test_omp_baseline_is_bit_identical_to_oracle(oracle, table_f64, mode, levels, win):
+    u, v = oracle.coarse_to_fine(*table_f64, levels, win)
+    uo, vo = oracle.omp_coarse_to_fine(*table_f64, levels, win, mode)
+    assert np.array_equal(u, uo) and np.array_equal(v, vo)
+
+
+def test_zero_motion_gives_zero_flow(oracle):
+    import synth
+    a = synth.smooth_noise(64, 96, seed=7)
+    u, v = oracle.coarse_to_fine(a, a, 3, 5)
+    assert not u.any() and not v.any()
+
+
+def test_translation_sign_and_magnitude(oracle):
+    import synth
+    a, b = synth.frame_pair(128, 192, seed=3, shift=(1.5, -0.75))
+    # single level: I2(x) = I1(x - d) -> flow ~ +d (the reference's 2x2 derivative taps sit half a
+    # pixel off-centre, so the estimate is biased by a few percent; the multi-level sum is NOT a
+    # metric flow because the reference adds pyrUp(u) without the x2 rescale)
+    u, v = oracle.coarse_to_fine(a, b, 1, 15)
+    core = (slice(24, -24), slice(24, -24))
+    assert abs(np.median(u[core]) - 1.5) < 0.25
+    assert abs(np.median(v[core]) + 0.75) < 0.15
+
+
+def test_window_generalisation_reduces_to_reference_at_3(oracle):
+    rng = np.random.default_rng(0)
+    m = rng.random((9, 11))
+    s = oracle.sum_win(m, 3)
+    want = np.zeros_like(m)
+    for i in range(1, 8):
+        for j in range(1, 10):
+            want[i, j] = m[i - 1:i + 2, j - 1:j + 2].sum()
+    assert np.allclose(s, want, rtol=0, atol=1e-14)
+    # clipped window rule at win=5: inside the 1-px ring but window clipped -> m*win^2
+    s5 = oracle.sum_win(m, 5)
+    assert s5[1, 1] == m[1, 1] * 25 and s5[0, 3] == 0.0
+    assert abs(s5[4, 5] - m[2:7, 3:8].sum()) < 1e-13
+
+
+def test_pyr_shapes_and_constants(oracle):
+    c = np.full((7, 10), 2.5)
+    d = oracle.pyr_down(c)
+    assert d.shape == (4, 5) and np.allclose(d, 2.5, atol=1e-15)
+    up = oracle.pyr_up(c)
+    assert up.shape == (14, 20) and np.allclose(up, 2.5, atol=1e-15)
+    one = oracle.pyr_up(np.array([[3.0]]))
+    assert one.shape == (2, 2) and np.allclose(one, 3.0)
+
+
+def test_remap_identity_and_border(oracle):
+    rng = np.random.default_rng(1)
+    img = rng.random((6, 8))
+    z = np.zeros((6, 8))
+    assert np.array_equal(oracle.remap_linear(img, oracle.build_map(z, z, 1.0)), img)
+    # a +2 px x-flow -> map1 = x + 1: last column samples outside -> border value 0 contributes
+    two = np.full((6, 8), 2.0)
+    w = oracle.remap_linear(img, oracle.build_map(two, z, 1.0))
+    assert np.array_equal(w[:, :-1], img[:, 1:]) and not w[:, -1].any()
+    # 1/32-px fixed point, round-half-even: 1/64 px rounds to 0
+    tiny = np.full((6, 8), 2.0 / 64)
+    assert np.array_equal(oracle.remap_linear(img, oracle.build_map(tiny, z, 1.0)), img)
+
+
+def test_flow_centroid(oracle):
+    u = np.zeros((5, 7)); v = np.zeros((5, 7))
+    u[2, 3] = 25.0; v[4, 6] = -30.0; u[0, 0] = 19.999
+    c, sx, sy = oracle.flow_centroid(u, v, 20.0)
+    assert (c, sx, sy) == (2, 9.0, 6.0)
