@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mpixels/s of dense pyramidal LK on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--config 1080p|4k|8k|pacman]
+
+One "step" = one pass of the hot path (lkflow_compute_batch_f64_dev: pyramids, coarse-to-fine
+warp + LK) over one batch of P synthetic frame pairs that are already resident in HBM.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); frame pairs are sharded, each
+rank owns P pairs (weak scaling) and there is NO collective on the data path -- only the
+barriers that bracket the timed region.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "optical-flow_amd"))
+
+CONFIGS = {
+    # name: (cols, rows, levels, win, default pairs/step/GPU)   -- BASELINE.json configs[1..4]
+    "1080p": (1920, 1080, 3, 15, 32),
+    "4k": (3840, 2160, 5, 21, 8),
+    "8k": (7680, 4320, 5, 31, 4),
+    "pacman": (240, 160, 3, 15, 244),
+}
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+
+
+def level_sizes(cols, rows, levels):
+    out = [(rows, cols)]
+    for _ in range(1, levels):
+        r, c = out[-1]
+        out.append(((r + 1) // 2, (c + 1) // 2))
+    return out
+
+
+def algorithmic_bytes_per_pair(cols, rows, levels):
+    """B_alg = sum_{l>=1} 2s(N_{l-1}+N_l) + sum_l s(4N_l + 2N_{l+1}), s = 8."""
+    n = [r * c for r, c in level_sizes(cols, rows, levels)] + [0]
+    s = 8
+    return sum(2 * s * (n[l - 1] + n[l]) for l in range(1, levels)) + \
+        sum(s * (4 * n[l] + 2 * n[l + 1]) for l in range(levels))
+
+
+def lk0_bytes_per_pair(cols, rows, levels):
+    """Algorithmic bytes of the dominant kernel (LK at level 0): read 2 images, read the coarse
+    u,v (N0/4 each), write u,v  = s(4 N0 + 2 N1)."""
+    n = [r * c for r, c in level_sizes(cols, rows, levels)] + [0]
+    return 8 * (4 * n[0] + 2 * n[1])
+
+
+def cpu_baseline(cols, rows, levels, win, budget_s=20.0):
+    """Times oracle/lk_cpu_omp.c (the restated ParallelVideoPyr.cpp CPU path) on this host."""
+    import synth
+    from oracle import oracle as O
+    O.build()
+    a, b = synth.frame_pair(rows, cols, seed=1234)
+    O.omp_coarse_to_fine(a[:64, :64].copy(), b[:64, :64].copy(), 1, 3, 0)   # thread pool warm-up
+    res = {}
+    for mode, name in ((0, "reference task structure"), (1, "all-cores row-parallel")):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.omp_coarse_to_fine(a, b, levels, win, mode)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s / 2 or n >= 8:
+                break
+        res[mode] = (n * rows * cols / dt / 1e6, n, dt, name)
+    cores = O.omp_lib().lkc_num_threads()
+    return {
+        "value": round(res[0][0], 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        "sample": f"{res[0][1]} pair(s) of {cols}x{rows} L{levels} w{win} in {res[0][2]:.1f}s with "
+                  f"oracle/lk_cpu_omp.c mode 0 (ParallelVideoPyr.cpp's 2/3/5-way tasks + 8-thread row loops)",
+        "all_cores_row_parallel_value": round(res[1][0], 4),
+        "all_cores_sample": f"{res[1][1]} pair(s) in {res[1][2]:.1f}s, mode 1, {cores} threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=0, help="frame pairs per step per GPU")
+    ap.add_argument("--config", default="1080p", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="HIP-event time of every stage")
+    args = ap.parse_args()
+
+    import torch
+    import lkflow_amd as lkf
+    import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cols, rows, levels, win, p_default = CONFIGS[args.config]
+    P = args.pairs or p_default
+    dev = torch.device("cuda", local_rank)
+
+    # synthetic translated-noise pairs generated in HBM (each rank: its own shard of the stream)
+    prev, nxt = synth.frame_pairs_torch(P, rows, cols, dev, seed=1234 + rank)
+    U = torch.empty_like(prev)
+    V = torch.empty_like(prev)
+    ctx = lkf.Context(local_rank)
+    ctx.reserve(rows, cols, levels, P)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ctx.compute_batch(prev, nxt, levels, win, out=(U, V), stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # dominant kernel (LK at level 0) bracketed by HIP events on its own stream, live in the timed region
+    if args.profile_all:
+        ctx.profile()
+    else:
+        ctx.profile(lkf.LKFLOW_STAGE_LK, 0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        px_per_step = P * rows * cols * world
+        value = px_per_step * args.steps / dt / 1e6
+        lk0_ms, lk0_n = prof[(lkf.LKFLOW_STAGE_LK, 0)]
+        lk0_avg_s = lk0_ms / lk0_n / 1e3
+        lk0_bytes = lk0_bytes_per_pair(cols, rows, levels) * P
+        achieved = lk0_bytes / lk0_avg_s
+        b_alg = algorithmic_bytes_per_pair(cols, rows, levels)
+        path_achieved = b_alg * P * args.steps / dt          # per GPU
+        out = {
+            "metric": f"Mpixels/s (dense LK, {levels}-level pyr, {win}x{win} win)",
+            "value": round(value, 2),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{cols}x{rows} synthetic translated-noise frame pairs, {levels} levels, "
+                            f"{win}x{win} window, {P} independent pairs per step per GPU (device-resident)",
+                "cols": cols, "rows": rows, "pyr_levels": levels, "win": win,
+                "pairs_per_step_per_gpu": P,
+                "parallelism": f"frame-pair sharding x{world} (no data-path collective)",
+            },
+            "frame_pairs_per_s": round(P * world * args.steps / dt, 2),
+            "roofline": {
+                "kernel": f"lk_march_kernel<{win},256,true> (LK at pyramid level 0)",
+                "bound": "hbm",
+                "achieved": round(achieved / 1e9, 2),
+                "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": lk0_bytes,
+                "avg_launch_ms": round(lk0_avg_s * 1e3, 4),
+                "launches_timed": lk0_n,
+            },
+            "path_roofline": {
+                "algorithmic_bytes_per_pair": b_alg,
+                "achieved_GBps_per_gpu": round(path_achieved / 1e9, 2),
+                "frac_of_8TBps": round(path_achieved / HBM_PEAK, 4),
+            },
+        }
+        if args.profile_all:
+            names = {0: "pyrdown", 1: "warp", 2: "lk"}
+            out["stage_ms_per_step"] = {f"{names[s]}_L{l}": round(ms / args.steps, 4)
+                                        for (s, l), (ms, n) in sorted(prof.items())}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cols, rows, levels, win)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

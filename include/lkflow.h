@@ -68,7 +68,21 @@ int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int 
 /* Tuning / debug knobs (never needed for correctness). */
 #define LKFLOW_OPT_IMPL 1      /* 0 = tiled marching kernels (default), 1 = per-pixel cross-check kernels */
 #define LKFLOW_OPT_TILE_ROWS 2 /* output rows per LK block; 0 = automatic */
+#define LKFLOW_OPT_PROFILE 3   /* 0 = off (default); -1 = bracket EVERY kernel launch with HIP events on
+                                  its own stream; 1 + stage*32 + level = only that (stage, level).
+                                  Read back with lkflow_ctx_profile_read. */
 int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value);
+
+/* Stage ids of the kernels the pyramid driver launches (level = pyramid level the launch works at;
+ * for PYRDOWN the destination level). */
+#define LKFLOW_STAGE_PYRDOWN 0
+#define LKFLOW_STAGE_WARP 1
+#define LKFLOW_STAGE_LK 2
+#define LKFLOW_N_STAGES 3
+#define LKFLOW_MAX_LEVELS 32
+/* Waits for the recorded events, then fills total_ms[stage*32 + level] / n_launches[stage*32 + level]
+ * (arrays of LKFLOW_N_STAGES*LKFLOW_MAX_LEVELS entries) and clears the records. */
+int lkflow_ctx_profile_read(lkflow_ctx *ctx, double *total_ms, int *n_launches);
 /* Bytes of device workspace currently held. */
 size_t lkflow_ctx_workspace_bytes(const lkflow_ctx *ctx);
 

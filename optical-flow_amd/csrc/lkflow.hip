@@ -41,6 +41,10 @@ struct lkflow_ctx {
     // options
     int impl = 0;
     int tile_rows = 0;
+    int profile = 0;
+    struct Rec { hipEvent_t a, b; int slot; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> ev_pool;
     // workspace arena
     char *arena = nullptr;
     size_t arena_bytes = 0;
@@ -68,6 +72,27 @@ bool hip_ok(lkflow_ctx *ctx, hipError_t e, const char *what)
     do {                                                     \
         if (!hip_ok((ctx), (call), #call)) return LKFLOW_E_HIP; \
     } while (0)
+
+// ---- optional per-launch HIP-event bracketing (LKFLOW_OPT_PROFILE) ------------------------------
+hipEvent_t ev_get(lkflow_ctx *ctx)
+{
+    if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    lkflow_ctx *ctx; hipStream_t s; bool on; hipEvent_t a = nullptr, b = nullptr; int slot;
+    ProfScope(lkflow_ctx *c, int stage, int level, hipStream_t st) : ctx(c), s(st), slot(stage * LKFLOW_MAX_LEVELS + level)
+    {
+        on = c->profile == -1 || c->profile == 1 + slot;
+        if (on) { a = ev_get(c); b = ev_get(c); (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope()
+    {
+        if (on) { (void)hipEventRecord(b, s); ctx->recs.push_back({a, b, slot}); }
+    }
+};
 
 int max_levels(int cols, int rows)
 {
@@ -260,6 +285,8 @@ void lkflow_ctx_destroy(lkflow_ctx *ctx)
     (void)hipDeviceSynchronize();
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->stage) (void)hipFree(ctx->stage);
+    for (auto &r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -276,11 +303,34 @@ int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value)
             if (value < 0 || value > 4096) return LKFLOW_E_ARG;
             ctx->tile_rows = value;
             return LKFLOW_OK;
+        case LKFLOW_OPT_PROFILE:
+            if (value < -1 || value > LKFLOW_N_STAGES * LKFLOW_MAX_LEVELS) return LKFLOW_E_ARG;
+            ctx->profile = value;
+            return LKFLOW_OK;
         default: return LKFLOW_E_ARG;
     }
 }
 
 size_t lkflow_ctx_workspace_bytes(const lkflow_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
+
+int lkflow_ctx_profile_read(lkflow_ctx *ctx, double *total_ms, int *n_launches)
+{
+    if (!ctx || !total_ms || !n_launches) return LKFLOW_E_ARG;
+    for (int i = 0; i < LKFLOW_N_STAGES * LKFLOW_MAX_LEVELS; ++i) { total_ms[i] = 0.0; n_launches[i] = 0; }
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    for (auto &r : ctx->recs) {
+        HIP_TRY(ctx, hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, r.a, r.b));
+        total_ms[r.slot] += ms;
+        n_launches[r.slot] += 1;
+        ctx->ev_pool.push_back(r.a);
+        ctx->ev_pool.push_back(r.b);
+    }
+    ctx->recs.clear();
+    return LKFLOW_OK;
+}
 
 int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int n_pairs)
 {
@@ -361,9 +411,11 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
     // a2: Gaussian pyramids of both frames (built from the ORIGINAL images, before any warp)
     for (int l = 1; l < L; ++l) {
         if (l == 1) {
+            ProfScope ps(ctx, LKFLOW_STAGE_PYRDOWN, 1, s);
             for (int f = 0; f < 2; ++f)
                 if ((rc = launch_pyrdown(ctx, pyr(0, f), lv[0].H, lv[0].W, pyr_w(1, f), P, s))) return rc;
         } else {
+            ProfScope ps(ctx, LKFLOW_STAGE_PYRDOWN, l, s);
             // frames 1 and 2 are adjacent in the arena: one launch over 2P planes
             if ((rc = launch_pyrdown(ctx, pyr(l - 1, 0), lv[l - 1].H, lv[l - 1].W, pyr_w(l, 0), 2 * P, s)))
                 return rc;
@@ -379,6 +431,7 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
         if (has_up) {
             CPlanes cu = as_c(flow_w(l + 1, 0)), cv = as_c(flow_w(l + 1, 1));
             // a9-a12: warp level l with the up-sampled flow of level l+1
+            ProfScope ps(ctx, LKFLOW_STAGE_WARP, l, s);
             if ((rc = launch_warp(ctx, pyr(l, 0), pyr(l, 1), lv[l].H, lv[l].W, cu, cv, warp_w(l, 0),
                                   warp_w(l, 1), P, s)))
                 return rc;
@@ -387,7 +440,10 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
         } else {
             a.i1 = pyr(l, 0); a.i2 = pyr(l, 1);
         }
-        if ((rc = launch_lk(ctx, a, has_up, P, win, s))) return rc;
+        {
+            ProfScope ps(ctx, LKFLOW_STAGE_LK, l, s);
+            if ((rc = launch_lk(ctx, a, has_up, P, win, s))) return rc;
+        }
     }
 
     // a12 at level 0: the reference's pyr[0] IS the caller's buffer, so its warp lands there

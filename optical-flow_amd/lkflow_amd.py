@@ -32,6 +32,9 @@ LKFLOW_MUTATE_INPUTS = 1
 LKFLOW_MAX_WIN = 31
 LKFLOW_OPT_IMPL = 1
 LKFLOW_OPT_TILE_ROWS = 2
+LKFLOW_OPT_PROFILE = 3
+LKFLOW_STAGE_PYRDOWN, LKFLOW_STAGE_WARP, LKFLOW_STAGE_LK = 0, 1, 2
+LKFLOW_N_STAGES, LKFLOW_MAX_LEVELS = 3, 32
 
 _vp = ctypes.c_void_p
 _sz = ctypes.c_size_t
@@ -50,6 +53,7 @@ SIGNATURES = {
     "lkflow_ctx_reserve": (_i, [_vp, _i, _i, _i, _i]),
     "lkflow_ctx_set_option": (_i, [_vp, _i, _i]),
     "lkflow_ctx_workspace_bytes": (_sz, [_vp]),
+    "lkflow_ctx_profile_read": (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(_i)]),
     "lkflow_compute_f64": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp, _vp, _sz, _i, _i, _u]),
     "lkflow_lk_f64": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp, _vp, _sz, _i]),
     "lkflow_compute_batch_f64_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _i, _i, _sz, _vp, _vp, _sz,
@@ -168,6 +172,25 @@ class Context:
 
     def reserve(self, rows, cols, levels, n_pairs=1):
         self._chk(lib().lkflow_ctx_reserve(self._h, rows, cols, levels, n_pairs))
+
+    def profile(self, stage=None, level=0):
+        """Bracket kernel launches with HIP events: profile() = all stages, profile(stage, level) =
+        one, profile(False) = off."""
+        if stage is False:
+            v = 0
+        elif stage is None:
+            v = -1
+        else:
+            v = 1 + stage * LKFLOW_MAX_LEVELS + level
+        self.set_option(LKFLOW_OPT_PROFILE, v)
+
+    def profile_read(self):
+        """-> {(stage, level): (total_ms, n_launches)} for everything recorded since the last read."""
+        n = LKFLOW_N_STAGES * LKFLOW_MAX_LEVELS
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_int * n)()
+        self._chk(lib().lkflow_ctx_profile_read(self._h, ms, cnt))
+        return {(i // LKFLOW_MAX_LEVELS, i % LKFLOW_MAX_LEVELS): (ms[i], cnt[i]) for i in range(n) if cnt[i]}
 
     @property
     def workspace_bytes(self):
