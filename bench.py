@@ -185,7 +185,7 @@ def main():
             },
             "frame_pairs_per_s": round(P * world * args.steps / dt, 2),
             "roofline": {
-                "kernel": f"lk_march_kernel<{win},256,true> (LK at pyramid level 0)",
+                "kernel": f"lk_march3_kernel<{win},256,true> (LK at pyramid level 0)",
                 "bound": "hbm",
                 "achieved": round(achieved / 1e9, 2),
                 "peak": HBM_PEAK / 1e9,

@@ -66,7 +66,7 @@ void lkflow_ctx_destroy(lkflow_ctx *ctx);
  * lazily with a stream-synchronising reallocation). */
 int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int n_pairs);
 /* Tuning / debug knobs (never needed for correctness). */
-#define LKFLOW_OPT_IMPL 1      /* 0 = tiled marching kernels (default), 1 = per-pixel cross-check kernels */
+#define LKFLOW_OPT_IMPL 1      /* 0 = row-marching LK kernel (default), 1 = per-pixel cross-check LK kernel */
 #define LKFLOW_OPT_TILE_ROWS 2 /* output rows per LK block; 0 = automatic */
 #define LKFLOW_OPT_PROFILE 3   /* 0 = off (default); -1 = bracket EVERY kernel launch with HIP events on
                                   its own stream; 1 + stage*32 + level = only that (stage, level).

@@ -4,7 +4,7 @@
 //   pyrdown_kernel        a2   cv::pyrDown of n planes
 //   pyrup_kernel          a9   cv::pyrUp (stage entry point / tests; the pipeline fuses it)
 //   warp_kernel           a9+a10+a11  pyrUp(flow) -> float map -> fixed-point bilinear remap
-//   lk_march_kernel<WIN>  a3..a8  derivatives, products, win x win sums, 2x2 solve, += pyrUp(flow)
+//   lk_march3_kernel<WIN> a3..a8  derivatives, products, win x win sums, 2x2 solve, += pyrUp(flow)  (lk_march3.h)
 //   lk_naive_kernel       a3..a8  per-pixel restatement (cross-check only)
 //   u8_to_f64_kernel      a15  convertTo(CV_64F, 1/255)
 //   centroid_kernel       f1   |flow| threshold + centroid sums
@@ -70,53 +70,7 @@ __global__ __launch_bounds__(256) void warp_kernel(CPlanes img1, CPlanes img2, i
     out2.at(p)[(long long)y * out2.pitch + x] = w2;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Single-level dense LK, row-marching kernel.
-//
-// Block = TX threads = TX adjacent image columns (one column per thread, coalesced 8-byte row
-// reads); the block marches down a strip of `th` output rows plus a 2R-row apron.
-//   per marched row:  stage I1,I2 row in LDS -> 2x2 derivative taps from the left neighbour ->
-//                     five products -> LDS -> horizontal WIN-tap sums (LDS row window)
-//   vertical WIN-tap sums: van Herk / Gil-Werman sliding sum held in REGISTERS -- prefix of the
-//                     current WIN-row chunk + suffix of the previous chunk; additions only (no
-//                     running subtract, so flat regions stay exactly 0 as in the reference).
-//   epilogue:         clipped-window rule (SerialPyr.cpp:94-95), 2x2 solve, divide-by-zero -> 0,
-//                     + pyrUp(coarse flow) (ParallelVideoPyr.cpp:634-637), store u,v.
-// Thread t owns column xc = x0 - R - 1 + t; t = 0 is a load-only column (left tap of t = 1);
-// threads R+1 .. TX-R-1 produce outputs, so a block yields TX - 2R - 1 columns.
-// ------------------------------------------------------------------------------------------------
-// One step of the vertical van Herk / Gil-Werman sliding sum at chunk position K (compile-time, so
-// that `ring` is indexed statically and lives in VGPRs):
-//   pre  = h_0 + ... + h_K                    (prefix of the current WIN-row chunk)
-//   S    = suffix_prev[K+1] + pre             (= sum of the last WIN rows)
-//   ring[K] = h_K; after the chunk's last row the ring is turned into suffix sums in place.
-template <int K, int WIN>
-__device__ __forceinline__ void vstep(double (&ring)[WIN][5], double (&pre)[5], const double (&h)[5],
-                                      double (&S)[5])
-{
-#pragma unroll
-    for (int f = 0; f < 5; ++f) {
-        pre[f] = (K == 0) ? h[f] : pre[f] + h[f];
-        S[f] = (K < WIN - 1) ? ring[(K + 1) % WIN][f] + pre[f] : pre[f];
-        ring[K][f] = h[f];
-    }
-    if (K == WIN - 1) {
-#pragma unroll
-        for (int q = WIN - 2; q >= 0; --q)
-#pragma unroll
-            for (int f = 0; f < 5; ++f) ring[q][f] += ring[q + 1][f];
-    }
-}
-
-template <int WIN, int... Ks>
-__device__ __forceinline__ void vstep_dispatch(int k, double (&ring)[WIN][5], double (&pre)[5],
-                                               const double (&h)[5], double (&S)[5],
-                                               std::integer_sequence<int, Ks...>)
-{
-    // wave-uniform k: a chain of scalar compares, each arm touching only constant ring slots
-    (void)((k == Ks ? (vstep<Ks, WIN>(ring, pre, h, S), true) : false) || ...);
-}
-
+// Arguments of the single-level LK kernels (lk_march3.h, lk_naive_kernel).
 struct LKArgs {
     CPlanes i1, i2;   // level images (H x W)
     Planes u, v;      // outputs (H x W)
@@ -124,116 +78,6 @@ struct LKArgs {
     int H, W;
     int th;           // output rows per block
 };
-
-template <int WIN, int TX, bool HAS_UP>
-__global__ __launch_bounds__(TX) void lk_march_kernel(LKArgs a)
-{
-    constexpr int R = WIN / 2;
-    constexpr int XO = TX - 2 * R - 1;
-    __shared__ double s_ab[2][2][TX];
-    __shared__ double s_p[2][5][TX + 2 * R];
-
-    const int t = threadIdx.x;
-    const int pair = blockIdx.z;
-    const int H = a.H, W = a.W;
-    const int x0 = blockIdx.x * XO;
-    const int xc = x0 - R - 1 + t;
-    const int y0 = blockIdx.y * a.th;
-    const int y1 = min(y0 + a.th, H);
-    const double *I1 = a.i1.at(pair), *I2 = a.i2.at(pair);
-    const long long pitch = a.i1.pitch;
-
-    const bool col_in = xc >= 0 && xc < W;
-    const int xl = col_in ? r101(xc - 1, W) : 0;
-    int tl = t + (xl - xc);
-    tl = col_in ? max(0, min(TX - 1, tl)) : t;
-    const bool is_out_col = t >= R + 1 && t < TX - R && xc < W;
-
-    const int nmarch = (y1 - y0) + 2 * R;
-    const int yy0 = y0 - R;
-
-    double ring[WIN][5];
-#pragma unroll
-    for (int q = 0; q < WIN; ++q)
-#pragma unroll
-        for (int f = 0; f < 5; ++f) ring[q][f] = 0.0;
-    double pre[5] = {0, 0, 0, 0, 0};
-    double pa = 0, pal = 0, pb = 0, pbl = 0;
-    bool have_prev = false;
-
-    int k = 0;  // position of the marched row inside its WIN-row chunk
-    for (int i = 0; i < nmarch; ++i) {
-        const int bsel = i & 1;  // double-buffered LDS rows
-        const int yy = yy0 + i;
-        const bool row_in = yy >= 0 && yy < H;
-        double ca = 0, cb = 0;
-        if (row_in) {
-            if (col_in) {
-                ca = I1[(long long)yy * pitch + xc];
-                cb = I2[(long long)yy * pitch + xc];
-            }
-            s_ab[bsel][0][t] = ca;
-            s_ab[bsel][1][t] = cb;
-            if (!have_prev) {
-                if (col_in) {
-                    const long long rp = (long long)r101(yy - 1, H) * pitch;
-                    pa = I1[rp + xc];
-                    pal = I1[rp + xl];
-                    pb = I2[rp + xc];
-                    pbl = I2[rp + xl];
-                }
-                have_prev = true;
-            }
-        }
-        __syncthreads();
-        double p[5] = {0, 0, 0, 0, 0};
-        if (row_in) {
-            const double cal = s_ab[bsel][0][tl], cbl = s_ab[bsel][1][tl];
-            if (col_in) lk_products(pal, pa, cal, ca, pbl, pb, cbl, cb, p);
-            pa = ca; pal = cal; pb = cb; pbl = cbl;
-        }
-#pragma unroll
-        for (int f = 0; f < 5; ++f) s_p[bsel][f][R + t] = p[f];
-        __syncthreads();
-
-        // horizontal WIN-tap sums
-        double h[5];
-#pragma unroll
-        for (int f = 0; f < 5; ++f) {
-            double s = s_p[bsel][f][t];
-#pragma unroll
-            for (int j = 1; j < WIN; ++j) s += s_p[bsel][f][t + j];
-            h[f] = s;
-        }
-
-        // vertical sliding sum (statically indexed register ring, dispatched on k)
-        double S[5];
-        vstep_dispatch<WIN>(k, ring, pre, h, S, std::make_integer_sequence<int, WIN>{});
-        k = (k == WIN - 1) ? 0 : k + 1;
-
-        const int y = yy - R;
-        if (i >= 2 * R && is_out_col) {
-            double u = 0.0, v = 0.0;
-            if (y >= 1 && y <= H - 2 && xc >= 1 && xc <= W - 2) {
-                const bool clipped = (y - R < 0) || (y + R > H - 1) || (xc - R < 0) ||
-                                     (xc + R > W - 1);
-                if (clipped) {  // SerialPyr.cpp:94-95: partial window -> m(y,x) * WIN^2
-                    double pc[5];
-                    lk_products_at(I1, I2, pitch, H, W, y, xc, pc);
-#pragma unroll
-                    for (int f = 0; f < 5; ++f) S[f] = pc[f] * (double)(WIN * WIN);
-                }
-                lk_solve(S, u, v);
-            }
-            if (HAS_UP) {
-                u += pyrup_at(a.cu.at(pair), a.cu.pitch, H >> 1, W >> 1, y, xc);
-                v += pyrup_at(a.cv.at(pair), a.cv.pitch, H >> 1, W >> 1, y, xc);
-            }
-            a.u.at(pair)[(long long)y * a.u.pitch + xc] = u;
-            a.v.at(pair)[(long long)y * a.v.pitch + xc] = v;
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Per-pixel LK (cross-check of the marching kernel on the GPU; reference summation order).

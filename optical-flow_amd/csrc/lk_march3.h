@@ -1,0 +1,224 @@
+// lk_march3.h -- single-level dense LK, row-marching kernel, one column per thread, lean body.
+//
+// Same stage semantics as lk_march_kernel (lk_kernels.h).  What bounds this kernel is fp64 VALU /
+// LDS instruction issue, so the body is organised for instruction count and for <= 256 VGPRs
+// (2 waves per SIMD):
+//   * thread t owns column x = x_base + t; per row: one 8-byte load per image + one for the left
+//     derivative tap (reflect-101 folded into the index), previous row carried in registers, next
+//     row prefetched;
+//   * horizontal WIN-tap sums: lanes 2j,2j+1 form the pair sum q_j = p(2j)+p(2j+1) with one DPP
+//     quad-permute (no LDS round trip); every lane stores p, even lanes store q; a window is then
+//     R pair sums + one single = R+1 LDS reads and R adds per field instead of WIN and WIN-1;
+//   * ONE barrier per marched row (double-buffered LDS rows);
+//   * vertical WIN-tap sums: van Herk / Gil-Werman prefix + suffix ring in REGISTERS, statically
+//     indexed (dispatch on the wave-uniform chunk position); additions only -- no running
+//     subtract, so flat regions stay exactly 0 like the reference;
+//   * "+= pyrUp(coarse flow)": the horizontally filtered coarse rows are carried in registers and
+//     refreshed every second fine row.
+#pragma once
+#include "lk_kernels.h"
+
+namespace lk {
+
+// swap with the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ double dpp_swap1(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int slo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+    const int shi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(shi, slo);
+}
+
+// Horizontal cv::pyrUp tap of one coarse row for ONE fine column (branch-free form of pyrup_h()):
+//   even x: (A + B*mB) + C2   interior A=c[j-1] mB=6 C2=c[j+1] | left A=0 mB=6 C2=c[1]*2
+//                             | right A=c[W-2] mB=7 C2=0 | single A=0 mB=8 C2=0
+//   odd x : (B + Co)*4        interior/left Co=c[j+1] | right/single Co=B  ((B+B)*4 == B*8 exactly)
+struct UpSel1 {
+    int jm, jc, jp;
+    double mB;
+    bool odd, keepA, dup;
+    int cmode;  // C2 = 0 (0), c[jp] (1), c[jp]*2 (2)
+};
+__device__ __forceinline__ UpSel1 make_upsel1(int x, int Wc)
+{
+    UpSel1 s;
+    int j = x >> 1;
+    j = j < 0 ? 0 : (j > Wc - 1 ? Wc - 1 : j);
+    s.jc = j;
+    s.jm = j > 0 ? j - 1 : 0;
+    s.jp = j < Wc - 1 ? j + 1 : Wc - 1;
+    const bool single = Wc == 1, left = j == 0, right = j == Wc - 1;
+    s.odd = (x & 1) != 0;
+    s.mB = single ? 8.0 : (right ? 7.0 : 6.0);
+    s.keepA = !(single || left);
+    s.cmode = (single || right) ? 0 : (left ? 2 : 1);
+    s.dup = single || right;
+    return s;
+}
+__device__ __forceinline__ double pyrup_h1(const double *c, const UpSel1 &s)
+{
+    const double B = c[s.jc], C = c[s.jp];
+    if (s.odd) return (B + (s.dup ? B : C)) * 4;
+    const double A = c[s.jm];
+    const double A1 = s.keepA ? A : 0.0;
+    const double C2 = s.cmode == 2 ? C * 2 : (s.cmode == 1 ? C : 0.0);
+    return (A1 + B * s.mB) + C2;
+}
+
+template <int WIN, int TX, bool HAS_UP>
+__global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKArgs a)
+{
+    constexpr int R = WIN / 2;
+    constexpr int XO = TX - 2 * R;            // output columns per block
+    constexpr int PP = 16, PQ = 8;            // LDS pads (only non-output threads read them)
+    __shared__ double s_p[2][5][TX + 2 * PP];
+    __shared__ double s_q[2][5][TX / 2 + 2 * PQ];
+
+    const int t = threadIdx.x;
+    const int pair = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int x = (int)blockIdx.x * XO - R + t;
+    const int y0 = blockIdx.y * a.th;
+    const int y1 = min(y0 + a.th, H);
+    const long long pitch = a.i1.pitch;
+    const bool col_in = x >= 0 && x < W;
+    const int xc = min(max(x, 0), W - 1);
+    const int xl = r101(xc - 1, W);
+    const double *I1c = a.i1.at(pair) + xc, *I2c = a.i2.at(pair) + xc;   // own column
+    const double *I1l = a.i1.at(pair) + xl, *I2l = a.i2.at(pair) + xl;   // left derivative tap
+    const bool is_out = t >= R && t < TX - R && x < W;
+
+    // window decomposition in thread-index space: threads [t-R, t+R] = R pairs + one single
+    const bool lead_single = ((t - R) & 1) != 0;               // (t-R) odd: single first
+    const int jb = (t - R + 1) >> 1;                           // first full pair (arithmetic shift)
+    const int sidx = lead_single ? t - R : t + R;              // the single tap
+
+    const int nmarch = (y1 - y0) + 2 * R;
+    const int yy0 = y0 - R;
+
+    double ring[WIN][5];
+#pragma unroll
+    for (int q = 0; q < WIN; ++q)
+#pragma unroll
+        for (int f = 0; f < 5; ++f) ring[q][f] = 0.0;
+    double pre[5] = {0, 0, 0, 0, 0};
+
+    // previous row (pa*, pb*) and prefetched current row (ca*, cb*): [0] = left tap, [1] = own
+    const int yfirst = max(yy0, 0);
+    long long ro = (long long)r101(yfirst - 1, H) * pitch;
+    double pa0 = I1l[ro], pa1 = I1c[ro], pb0 = I2l[ro], pb1 = I2c[ro];
+    ro = (long long)yfirst * pitch;
+    double ca0 = I1l[ro], ca1 = I1c[ro], cb0 = I2l[ro], cb1 = I2c[ro];
+
+    [[maybe_unused]] UpSel1 us{};
+    [[maybe_unused]] double hu[3] = {0, 0, 0}, hv[3] = {0, 0, 0};   // carried coarse rows s(i-1),s(i),s(i+1)
+    [[maybe_unused]] const int Hc = H >> 1;
+    [[maybe_unused]] const double *CU = nullptr, *CV = nullptr;
+    [[maybe_unused]] int up_i = -1000000;
+    if (HAS_UP) {
+        us = make_upsel1(xc, W >> 1);
+        CU = a.cu.at(pair);
+        CV = a.cv.at(pair);
+    }
+    auto up_srow = [&](int k) { return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };
+
+    // One marched row at chunk position K (compile-time): the chunk loop below is unrolled WIN
+    // times so that every ring access is a plain register (no dispatch, no copies).
+    auto row = [&](auto kc, int i) __attribute__((always_inline)) {
+        constexpr int K = decltype(kc)::value;
+        const int bsel = i & 1;
+        const int yy = yy0 + i;
+        double p[5] = {0, 0, 0, 0, 0};
+        if (yy >= 0 && yy < H) {
+            double na0 = 0, na1 = 0, nb0 = 0, nb1 = 0;
+            if (yy + 1 < H) {                                   // prefetch the next row
+                const long long rn = (long long)(yy + 1) * pitch;
+                na0 = I1l[rn]; na1 = I1c[rn]; nb0 = I2l[rn]; nb1 = I2c[rn];
+            }
+            lk_products(pa0, pa1, ca0, ca1, pb0, pb1, cb0, cb1, p);
+            if (!col_in) {
+#pragma unroll
+                for (int f = 0; f < 5; ++f) p[f] = 0.0;
+            }
+            pa0 = ca0; pa1 = ca1; pb0 = cb0; pb1 = cb1;
+            ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
+        }
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const double q = p[f] + dpp_swap1(p[f]);
+            s_p[bsel][f][PP + t] = p[f];
+            if ((t & 1) == 0) s_q[bsel][f][PQ + (t >> 1)] = q;
+        }
+        __syncthreads();
+
+        double S[5];
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const double *q = &s_q[bsel][f][PQ + jb];
+            double h = s_p[bsel][f][PP + sidx];
+#pragma unroll
+            for (int j = 0; j < R; ++j) h += q[j];
+            // vertical van Herk / Gil-Werman step at static chunk position K
+            pre[f] = (K == 0) ? h : pre[f] + h;
+            S[f] = (K < WIN - 1) ? ring[(K + 1) % WIN][f] + pre[f] : pre[f];
+            ring[K][f] = h;
+        }
+        if (K == WIN - 1) {
+#pragma unroll
+            for (int q = WIN - 2; q >= 0; --q)
+#pragma unroll
+                for (int f = 0; f < 5; ++f) ring[q][f] += ring[q + 1][f];
+        }
+
+        const int y = yy - R;
+        if (i >= 2 * R && is_out) {
+            double u = 0.0, v = 0.0;
+            if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
+                const bool clipped = (y - R < 0) || (y + R > H - 1) || (x - R < 0) || (x + R > W - 1);
+                if (clipped) {  // SerialPyr.cpp:94-95: partial window -> m(y,x) * WIN^2
+                    double pc[5];
+                    lk_products_at(a.i1.at(pair), a.i2.at(pair), pitch, H, W, y, x, pc);
+#pragma unroll
+                    for (int f = 0; f < 5; ++f) S[f] = pc[f] * (double)(WIN * WIN);
+                }
+                lk_solve(S, u, v);
+            }
+            if (HAS_UP) {
+                const int ci = y >> 1;
+                if (ci != up_i) {                               // every second fine row
+                    if (ci == up_i + 1) {
+                        hu[0] = hu[1]; hu[1] = hu[2]; hv[0] = hv[1]; hv[1] = hv[2];
+                        const int sr = up_srow(ci + 1);
+                        hu[2] = pyrup_h1(CU + (long long)sr * a.cu.pitch, us);
+                        hv[2] = pyrup_h1(CV + (long long)sr * a.cv.pitch, us);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) {
+                            const int sr = up_srow(ci - 1 + s);
+                            hu[s] = pyrup_h1(CU + (long long)sr * a.cu.pitch, us);
+                            hv[s] = pyrup_h1(CV + (long long)sr * a.cv.pitch, us);
+                        }
+                    }
+                    up_i = ci;
+                }
+                if (y & 1) {
+                    u += ((hu[1] + hu[2]) * 4) * (1.0 / 64);
+                    v += ((hv[1] + hv[2]) * 4) * (1.0 / 64);
+                } else {
+                    u += (hu[0] + hu[1] * 6 + hu[2]) * (1.0 / 64);
+                    v += (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);
+                }
+            }
+            a.u.at(pair)[(long long)y * a.u.pitch + x] = u;
+            a.v.at(pair)[(long long)y * a.v.pitch + x] = v;
+        }
+    };
+
+    for (int base = 0; base < nmarch; base += WIN) {
+        [&]<int... Ks>(std::integer_sequence<int, Ks...>) __attribute__((always_inline)) {
+            ((base + Ks < nmarch ? (row(std::integral_constant<int, Ks>{}, base + Ks), 0) : 0), ...);
+        }(std::make_integer_sequence<int, WIN>{});
+    }
+}
+
+}  // namespace lk

@@ -10,12 +10,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/lkflow.h"
 #include "lk_kernels.h"
+#include "lk_march3.h"
 
 #define LKFLOW_VERSION_STR "lkflow-mi355x 0.1 (gfx950)"
 
@@ -167,15 +169,38 @@ inline double *arena_at(lkflow_ctx *ctx, long long off_elems)
 inline dim3 grid_px(int W, int H, int planes) { return dim3((W + 63) / 64, (H + 3) / 4, planes); }
 
 // ---- LK launch ---------------------------------------------------------------------------------
-constexpr int LK_TX = 256;
 
-template <int WIN>
-void launch_lk_win(const lk::LKArgs &a, bool has_up, dim3 grid, hipStream_t s)
+template <int WIN, int TX>
+void launch_lk3_win(const lk::LKArgs &a, bool has_up, dim3 grid, hipStream_t s)
 {
     if (has_up)
-        hipLaunchKernelGGL((lk::lk_march_kernel<WIN, LK_TX, true>), grid, dim3(LK_TX), 0, s, a);
+        hipLaunchKernelGGL((lk::lk_march3_kernel<WIN, TX, true>), grid, dim3(TX), 0, s, a);
     else
-        hipLaunchKernelGGL((lk::lk_march_kernel<WIN, LK_TX, false>), grid, dim3(LK_TX), 0, s, a);
+        hipLaunchKernelGGL((lk::lk_march3_kernel<WIN, TX, false>), grid, dim3(TX), 0, s, a);
+}
+
+template <int TX>
+int launch_lk3(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hipStream_t s)
+{
+    const int R = win / 2;
+    const int xo = TX - 2 * R;
+    const int gx = (a.W + xo - 1) / xo;
+    int th = ctx->tile_rows;
+    if (th <= 0) {
+        th = 256;
+        while (th > 32 && (long long)gx * ((a.H + th - 1) / th) * pairs < 2048) th >>= 1;
+    }
+    if (th > a.H) th = a.H;
+    a.th = th;
+    dim3 grid(gx, (a.H + th - 1) / th, pairs);
+    switch (win) {
+#define LK_CASE(WN) case WN: launch_lk3_win<WN, TX>(a, has_up, grid, s); break;
+        LK_CASE(3) LK_CASE(5) LK_CASE(7) LK_CASE(9) LK_CASE(11) LK_CASE(13) LK_CASE(15) LK_CASE(17)
+        LK_CASE(19) LK_CASE(21) LK_CASE(23) LK_CASE(25) LK_CASE(27) LK_CASE(29) LK_CASE(31)
+#undef LK_CASE
+        default: return LKFLOW_E_WIN;
+    }
+    return LKFLOW_OK;
 }
 
 int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hipStream_t s)
@@ -187,26 +212,13 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
         HIP_TRY(ctx, hipGetLastError());
         return LKFLOW_OK;
     }
-    const int R = win / 2;
-    const int xo = LK_TX - 2 * R - 1;
-    const int gx = (a.W + xo - 1) / xo;
-    int th = ctx->tile_rows;
-    if (th <= 0) {
-        th = 128;
-        while (th > 16 && (long long)gx * ((a.H + th - 1) / th) * pairs < 2048) th >>= 1;
+    if (ctx->impl == 0) {
+        int rc = launch_lk3<256>(ctx, a, has_up, pairs, win, s);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipGetLastError());
+        return LKFLOW_OK;
     }
-    if (th > a.H) th = a.H;
-    a.th = th;
-    dim3 grid(gx, (a.H + th - 1) / th, pairs);
-    switch (win) {
-#define LK_CASE(WN) case WN: launch_lk_win<WN>(a, has_up, grid, s); break;
-        LK_CASE(3) LK_CASE(5) LK_CASE(7) LK_CASE(9) LK_CASE(11) LK_CASE(13) LK_CASE(15) LK_CASE(17)
-        LK_CASE(19) LK_CASE(21) LK_CASE(23) LK_CASE(25) LK_CASE(27) LK_CASE(29) LK_CASE(31)
-#undef LK_CASE
-        default: return LKFLOW_E_WIN;
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    return LKFLOW_OK;
+    return LKFLOW_E_ARG;
 }
 
 int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int planes, hipStream_t s)
