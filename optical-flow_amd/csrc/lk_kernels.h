@@ -16,26 +16,86 @@
 namespace lk {
 
 // ------------------------------------------------------------------------------------------------
-// cv::pyrDown.  One thread per output pixel; horizontal [1 4 6 4 1] on five source rows, then
-// vertical, then * 1/256 -- same expression order as OpenCV 2.4 pyrDown_.
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), so
+// with the natural order vertically adjacent tiles -- which share halo rows -- land on different L2s
+// and the halo is fetched from HBM once per XCD.  tile_id() gives every XCD one contiguous run of
+// the row-major tile sequence instead (bijective for any tile count).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pyrdown_kernel(CPlanes src, int H, int W, Planes dst, int Hd,
-                                                      int Wd)
+__device__ __forceinline__ unsigned xcd_tile_id(unsigned lin, unsigned n)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= Wd || y >= Hd) return;
-    const double *s = src.at(blockIdx.z);
-    const int xc = r101(2 * x, W), xl1 = r101(2 * x - 1, W), xr1 = r101(2 * x + 1, W);
-    const int xl2 = r101(2 * x - 2, W), xr2 = r101(2 * x + 2, W);
-    double row[5];
+    const unsigned xcd = lin & 7u, q = n >> 3, r = n & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::pyrDown.  One thread = a 2x2 quad of OUTPUT pixels = a 7x7 source patch read as 16-byte
+// pairs (interior) or reflect-101 clamped scalars (border); horizontal [1 4 6 4 1] per source row,
+// then vertical, then * 1/256 -- same expression order as OpenCV 2.4 pyrDown_.
+// Block = 64 x 4 threads = a 128 x 8 output tile; 1-D grid over (planes, tile rows, tile cols).
+// ------------------------------------------------------------------------------------------------
+struct PyrDownArgs {
+    CPlanes src;
+    Planes dst;
+    int H, W, Hd, Wd;
+    int gx, gy;        // tiles per plane
+    int vec_src;       // src: 16-byte aligned base, even pitch/plane -> double2 loads
+    int vec_dst;
+};
+
+__global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
+{
+    const unsigned n = gridDim.x;
+    unsigned tile = xcd_tile_id(blockIdx.x, n);
+    const int bx = tile % a.gx; tile /= a.gx;
+    const int by = tile % a.gy;
+    const int plane = tile / a.gy;
+    const int xo = (bx * 64 + (threadIdx.x & 63)) * 2;      // first output column of the quad
+    const int yo = (by * 4 + (threadIdx.x >> 6)) * 2;       // first output row
+    if (xo >= a.Wd || yo >= a.Hd) return;
+    const int H = a.H, W = a.W;
+    const double *s = a.src.at(plane);
+    const int pitch = (int)a.src.pitch;
+    const int xs = 2 * xo - 2;                              // first source column (even)
+    const bool fast = a.vec_src && xs >= 0 && xs + 6 < W;
+    int cx[7];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const double *r = s + (long long)r101(2 * y + k - 2, H) * src.pitch;
-        row[k] = r[xc] * 6 + (r[xl1] + r[xr1]) * 4 + r[xl2] + r[xr2];
+    for (int k = 0; k < 7; ++k) cx[k] = r101(xs + k, W);
+
+    double h0[7], h1[7];                                    // horizontal results of the 7 source rows
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double *r = s + r101(2 * yo - 2 + k, H) * pitch;
+        double v[7];
+        if (fast) {
+            const double2 p0 = *reinterpret_cast<const double2 *>(r + xs);
+            const double2 p1 = *reinterpret_cast<const double2 *>(r + xs + 2);
+            const double2 p2 = *reinterpret_cast<const double2 *>(r + xs + 4);
+            v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y;
+            v[6] = r[xs + 6];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = r[cx[j]];
+        }
+        h0[k] = v[2] * 6 + (v[1] + v[3]) * 4 + v[0] + v[4];
+        h1[k] = v[4] * 6 + (v[3] + v[5]) * 4 + v[2] + v[6];
     }
-    dst.at(blockIdx.z)[(long long)y * dst.pitch + x] =
-        (row[2] * 6 + (row[1] + row[3]) * 4 + row[0] + row[4]) * (1.0 / 256);
+    const double o00 = (h0[2] * 6 + (h0[1] + h0[3]) * 4 + h0[0] + h0[4]) * (1.0 / 256);
+    const double o01 = (h1[2] * 6 + (h1[1] + h1[3]) * 4 + h1[0] + h1[4]) * (1.0 / 256);
+    const double o10 = (h0[4] * 6 + (h0[3] + h0[5]) * 4 + h0[2] + h0[6]) * (1.0 / 256);
+    const double o11 = (h1[4] * 6 + (h1[3] + h1[5]) * 4 + h1[2] + h1[6]) * (1.0 / 256);
+    double *d = a.dst.at(plane) + yo * (int)a.dst.pitch + xo;
+    const bool two_c = xo + 1 < a.Wd, two_r = yo + 1 < a.Hd;
+    if (two_c && a.vec_dst) {
+        *reinterpret_cast<double2 *>(d) = make_double2(o00, o01);
+        if (two_r) *reinterpret_cast<double2 *>(d + a.dst.pitch) = make_double2(o10, o11);
+    } else {
+        d[0] = o00;
+        if (two_c) d[1] = o01;
+        if (two_r) {
+            d[a.dst.pitch] = o10;
+            if (two_c) d[a.dst.pitch + 1] = o11;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -53,23 +113,82 @@ __global__ __launch_bounds__(256) void pyrup_kernel(CPlanes src, int Hc, int Wc,
 
 // ------------------------------------------------------------------------------------------------
 // Warp of one pyramid level: up-sample the coarse flow, build the float map, remap both images.
-// ParallelVideoPyr.cpp:646-703.  H, W are the fine level's size (= 2*Hc, 2*Wc).
+// ParallelVideoPyr.cpp:646-703.  H, W are the fine level's size (= 2*Hc, 2*Wc, both even).
+// One thread = a 2x2 quad of fine pixels, which shares one 3x3 coarse neighbourhood per flow
+// plane for cv::pyrUp (branch-free border handling, same roundings as pyrup_at()); 32 independent
+// gather loads per thread keep the memory pipe busy; 16-byte stores.
+// Block = 64 x 4 threads = a 128 x 8 pixel tile; XCD-aware 1-D grid.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void warp_kernel(CPlanes img1, CPlanes img2, int H, int W,
-                                                   CPlanes cu, CPlanes cv, Planes out1, Planes out2)
+struct WarpArgs {
+    CPlanes img1, img2, cu, cv;
+    Planes out1, out2;
+    int H, W;
+    int gx, gy;
+    int vec_out;
+};
+
+__device__ __forceinline__ void pyrup_quad(const double *c, int cp, int Hc, int Wc, int i, int j,
+                                           double (&o)[2][2])
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const int p = blockIdx.z;
-    const double upu = pyrup_at(cu.at(p), cu.pitch, H >> 1, W >> 1, y, x);
-    const double upv = pyrup_at(cv.at(p), cv.pitch, H >> 1, W >> 1, y, x);
-    double w1, w2;
-    warp_pair_at(img1.at(p), img2.at(p), img1.pitch, H, W, y, x, upu, upv, w1, w2);
-    out1.at(p)[(long long)y * out1.pitch + x] = w1;
-    out2.at(p)[(long long)y * out2.pitch + x] = w2;
+    const int jm = j > 0 ? j - 1 : 0, jp = j < Wc - 1 ? j + 1 : Wc - 1;
+    const bool single = Wc == 1, left = j == 0, right = j == Wc - 1;
+    const double mB = single ? 8.0 : (right ? 7.0 : 6.0);
+    const double wA = (single || left) ? 0.0 : 1.0;
+    const double wC = (single || right) ? 0.0 : (left ? 2.0 : 1.0);
+    const bool dup = single || right;
+    const int s0 = i - 1 < 0 ? min(1, Hc - 1) : i - 1;      // r101(2k, 2Hc)/2
+    const int s2 = i + 1 > Hc - 1 ? Hc - 1 : i + 1;
+    const int srow[3] = {s0, i, s2};
+    double ev[3], od[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double *r = c + srow[k] * cp;
+        const double A = r[jm], B = r[j], C = r[jp];
+        ev[k] = (A * wA + B * mB) + C * wC;
+        od[k] = (B + (dup ? B : C)) * 4;
+    }
+    o[0][0] = (ev[0] + ev[1] * 6 + ev[2]) * (1.0 / 64);
+    o[0][1] = (od[0] + od[1] * 6 + od[2]) * (1.0 / 64);
+    o[1][0] = ((ev[1] + ev[2]) * 4) * (1.0 / 64);
+    o[1][1] = ((od[1] + od[2]) * 4) * (1.0 / 64);
 }
 
+__global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
+{
+    const unsigned n = gridDim.x;
+    unsigned tile = xcd_tile_id(blockIdx.x, n);
+    const int bx = tile % a.gx; tile /= a.gx;
+    const int by = tile % a.gy;
+    const int p = tile / a.gy;
+    const int x = (bx * 64 + (threadIdx.x & 63)) * 2;
+    const int y = (by * 4 + (threadIdx.x >> 6)) * 2;
+    const int H = a.H, W = a.W;
+    if (x >= W || y >= H) return;
+    double upu[2][2], upv[2][2];
+    pyrup_quad(a.cu.at(p), (int)a.cu.pitch, H >> 1, W >> 1, y >> 1, x >> 1, upu);
+    pyrup_quad(a.cv.at(p), (int)a.cv.pitch, H >> 1, W >> 1, y >> 1, x >> 1, upv);
+    const double *I1 = a.img1.at(p), *I2 = a.img2.at(p);
+    const long long ip = a.img1.pitch;
+    double w1[2][2], w2[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+            warp_pair_at(I1, I2, ip, H, W, y + dy, x + dx, upu[dy][dx], upv[dy][dx], w1[dy][dx], w2[dy][dx]);
+    double *o1 = a.out1.at(p) + y * (int)a.out1.pitch + x;
+    double *o2 = a.out2.at(p) + y * (int)a.out2.pitch + x;
+    if (a.vec_out) {
+        *reinterpret_cast<double2 *>(o1) = make_double2(w1[0][0], w1[0][1]);
+        *reinterpret_cast<double2 *>(o1 + a.out1.pitch) = make_double2(w1[1][0], w1[1][1]);
+        *reinterpret_cast<double2 *>(o2) = make_double2(w2[0][0], w2[0][1]);
+        *reinterpret_cast<double2 *>(o2 + a.out2.pitch) = make_double2(w2[1][0], w2[1][1]);
+    } else {
+        o1[0] = w1[0][0]; o1[1] = w1[0][1]; o1[a.out1.pitch] = w1[1][0]; o1[a.out1.pitch + 1] = w1[1][1];
+        o2[0] = w2[0][0]; o2[1] = w2[0][1]; o2[a.out2.pitch] = w2[1][0]; o2[a.out2.pitch + 1] = w2[1][1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Arguments of the single-level LK kernels (lk_march3.h, lk_naive_kernel).
 struct LKArgs {
     CPlanes i1, i2;   // level images (H x W)

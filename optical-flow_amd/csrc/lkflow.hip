@@ -38,6 +38,7 @@ struct Level {
 
 struct lkflow_ctx {
     int device = 0;
+    int n_cu = 256;
     hipStream_t own_stream = nullptr;
     std::string last_error;
     // options
@@ -112,6 +113,9 @@ int check_common(int rows, int cols, size_t step_bytes, size_t uv_step_bytes, in
     if (rows < 1 || cols < 1 || n_pairs < 1 || n_pairs > 32767) return LKFLOW_E_ARG;
     if (step_bytes < (size_t)cols * 8 || step_bytes % 8) return LKFLOW_E_ARG;
     if (uv_step_bytes < (size_t)cols * 8 || uv_step_bytes % 8) return LKFLOW_E_ARG;
+    // kernels index one plane with 32-bit element offsets
+    if ((unsigned long long)rows * (step_bytes / 8) >= (1ull << 31)) return LKFLOW_E_ARG;
+    if ((unsigned long long)rows * (uv_step_bytes / 8) >= (1ull << 31)) return LKFLOW_E_ARG;
     return LKFLOW_OK;
 }
 
@@ -170,9 +174,52 @@ inline dim3 grid_px(int W, int H, int planes) { return dim3((W + 63) / 64, (H + 
 
 // ---- LK launch ---------------------------------------------------------------------------------
 
-template <int WIN, int TX>
-void launch_lk3_win(const lk::LKArgs &a, bool has_up, dim3 grid, hipStream_t s)
+// Resident blocks per CU of one LK instantiation (occupancy query, cached per process).
+template <int WIN, int TX, bool HAS_UP>
+int lk3_blocks_per_cu()
 {
+    static int cached = 0;
+    if (cached == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lk::lk_march3_kernel<WIN, TX, HAS_UP>, TX, 0) !=
+                hipSuccess || n < 1)
+            n = 1;
+        cached = n;
+    }
+    return cached;
+}
+
+// Rows per block: every block marches th + 2R rows and blocks run in rounds of `slots` resident
+// blocks -> minimise rounds * (th + 2R + fixed cost) over the number of row strips.
+inline int pick_tile_rows(int H, int R, long long blocks_per_strip, long long slots)
+{
+    long long best = -1;
+    int th = H;
+    for (int gy = 1; gy <= H; ++gy) {
+        const int t = (H + gy - 1) / gy;
+        if (t < 24 && gy > 1) break;
+        if ((H + t - 1) / t != gy) continue;
+        const long long nblk = blocks_per_strip * gy;
+        const long long cost = ((nblk + slots - 1) / slots) * (t + 2 * R + 6);
+        if (best < 0 || cost < best) { best = cost; th = t; }
+    }
+    return th;
+}
+
+template <int WIN, int TX>
+void launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
+{
+    constexpr int R = WIN / 2;
+    constexpr int xo = TX - 2 * R;
+    const int gx = (a.W + xo - 1) / xo;
+    int th = ctx->tile_rows;
+    if (th <= 0) {
+        const int bpc = has_up ? lk3_blocks_per_cu<WIN, TX, true>() : lk3_blocks_per_cu<WIN, TX, false>();
+        th = pick_tile_rows(a.H, R, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
+    }
+    if (th > a.H) th = a.H;
+    a.th = th;
+    dim3 grid(gx, (a.H + th - 1) / th, pairs);
     if (has_up)
         hipLaunchKernelGGL((lk::lk_march3_kernel<WIN, TX, true>), grid, dim3(TX), 0, s, a);
     else
@@ -180,23 +227,16 @@ void launch_lk3_win(const lk::LKArgs &a, bool has_up, dim3 grid, hipStream_t s)
 }
 
 template <int TX>
-int launch_lk3(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hipStream_t s)
+int launch_lk3(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, int win, hipStream_t s)
 {
-    const int R = win / 2;
-    const int xo = TX - 2 * R;
-    const int gx = (a.W + xo - 1) / xo;
-    int th = ctx->tile_rows;
-    if (th <= 0) {
-        th = 256;
-        while (th > 32 && (long long)gx * ((a.H + th - 1) / th) * pairs < 2048) th >>= 1;
-    }
-    if (th > a.H) th = a.H;
-    a.th = th;
-    dim3 grid(gx, (a.H + th - 1) / th, pairs);
     switch (win) {
-#define LK_CASE(WN) case WN: launch_lk3_win<WN, TX>(a, has_up, grid, s); break;
+#define LK_CASE(WN) case WN: launch_lk3_win<WN, TX>(ctx, a, has_up, pairs, s); break;
+#ifdef LKFLOW_FAST_BUILD   /* A/B experiment builds: only the windows the goldens / headline use */
+        LK_CASE(3) LK_CASE(15)
+#else
         LK_CASE(3) LK_CASE(5) LK_CASE(7) LK_CASE(9) LK_CASE(11) LK_CASE(13) LK_CASE(15) LK_CASE(17)
         LK_CASE(19) LK_CASE(21) LK_CASE(23) LK_CASE(25) LK_CASE(27) LK_CASE(29) LK_CASE(31)
+#endif
 #undef LK_CASE
         default: return LKFLOW_E_WIN;
     }
@@ -221,11 +261,22 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
     return LKFLOW_E_ARG;
 }
 
+inline bool vec16(const void *p, long long plane, long long pitch)
+{
+    return ((uintptr_t)p % 16 == 0) && (plane % 2 == 0) && (pitch % 2 == 0);
+}
+
 int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int planes, hipStream_t s)
 {
-    const int Hd = (H + 1) / 2, Wd = (W + 1) / 2;
-    hipLaunchKernelGGL(lk::pyrdown_kernel, grid_px(Wd, Hd, planes), dim3(256), 0, s, src, H, W, dst,
-                       Hd, Wd);
+    lk::PyrDownArgs a{};
+    a.src = src; a.dst = dst; a.H = H; a.W = W;
+    a.Hd = (H + 1) / 2; a.Wd = (W + 1) / 2;
+    a.gx = (a.Wd + 127) / 128; a.gy = (a.Hd + 7) / 8;
+    a.vec_src = vec16(src.base, src.plane, src.pitch);
+    a.vec_dst = vec16(dst.base, dst.plane, dst.pitch);
+    const long long n = (long long)a.gx * a.gy * planes;
+    if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
+    hipLaunchKernelGGL(lk::pyrdown_kernel, dim3((unsigned)n), dim3(256), 0, s, a);
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }
@@ -233,8 +284,14 @@ int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int p
 int launch_warp(lkflow_ctx *ctx, CPlanes i1, CPlanes i2, int H, int W, CPlanes cu, CPlanes cv,
                 Planes o1, Planes o2, int pairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(lk::warp_kernel, grid_px(W, H, pairs), dim3(256), 0, s, i1, i2, H, W, cu, cv,
-                       o1, o2);
+    lk::WarpArgs a{};
+    a.img1 = i1; a.img2 = i2; a.cu = cu; a.cv = cv; a.out1 = o1; a.out2 = o2;
+    a.H = H; a.W = W;
+    a.gx = (W + 127) / 128; a.gy = (H + 7) / 8;
+    a.vec_out = vec16(o1.base, o1.plane, o1.pitch) && vec16(o2.base, o2.plane, o2.pitch);
+    const long long n = (long long)a.gx * a.gy * pairs;
+    if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
+    hipLaunchKernelGGL(lk::warp_kernel, dim3((unsigned)n), dim3(256), 0, s, a);
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }
@@ -286,6 +343,9 @@ int lkflow_ctx_create(lkflow_ctx **out, int device)
         delete ctx;
         return LKFLOW_E_HIP;
     }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
+        ctx->n_cu = ncu;
     *out = ctx;
     return LKFLOW_OK;
 }

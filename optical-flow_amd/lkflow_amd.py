@@ -18,7 +18,7 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblkflow.so")
+LIB_PATH = os.environ.get("LKFLOW_LIB") or os.path.join(_HERE, "liblkflow.so")   # LKFLOW_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lkflow.h")
 
 LKFLOW_OK = 0

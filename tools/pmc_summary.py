@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs (tools/prof_pmc.sh): per kernel, mean counter value per dispatch
+over the dispatches of the LARGEST grid of that kernel (= the level-0 launches)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))     # kernel -> counter -> [values of largest-grid dispatches]
+grid = defaultdict(int)
+rows = []
+for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            name = r["Kernel_Name"]
+            if not name.startswith(("lk::", "void lk::")):
+                continue
+            short = name.replace("void ", "").split("(")[0]
+            g = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0))
+            rows.append((short, g, r["Counter_Name"], float(r["Counter_Value"]), r))
+            grid[short] = max(grid[short], g)
+for short, g, cname, val, r in rows:
+    if g == grid[short]:
+        acc[short][cname].append(val)
+for k in sorted(acc):
+    print(f"== {k}  (grid {grid[k]} work-items)")
+    c = {n: sum(v) / len(v) for n, v in acc[k].items()}
+    for n in sorted(c):
+        print(f"   {n:32s} {c[n]:18.1f}")
+    if "FETCH_SIZE" in c:
+        # FETCH_SIZE is in KiB and (gfx950) counts 128-B requests as 64 B: x2 (MI355X_MICROARCH.md, HBM)
+        print(f"   -> HBM read  ~ {c['FETCH_SIZE'] * 1024 * 2 / 1e6:10.1f} MB/launch (FETCH_SIZE KiB x2 correction)")
+    if "WRITE_SIZE" in c:
+        print(f"   -> HBM write ~ {c['WRITE_SIZE'] * 1024 / 1e6:10.1f} MB/launch")
+    if "SQ_WAVES" in c and c["SQ_WAVES"]:
+        w = c["SQ_WAVES"]
+        for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"):
+            if n in c:
+                print(f"   -> {n}/wave = {c[n] / w:10.1f}")
