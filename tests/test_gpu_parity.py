@@ -258,3 +258,20 @@ def test_error_codes(gpu_ctx, lkflow, torch):
     assert L.lkflow_compute_batch_f64_dev(gpu_ctx._h, a.data_ptr(), a.data_ptr(), 0, 0, 1, 64, 96, 8 * 95,
                                           a.data_ptr(), a.data_ptr(), 0, 8 * 96, 1, 3, 0,
                                           None) == lkflow.LKFLOW_E_ARG   # step < cols*8
+
+
+def test_stream_leg_u8_frames_to_flow_and_centroid(gpu_ctx, oracle, torch):
+    """The per-rank GPU leg of the sharded video path (sharding.stream_flow): uint8 frames in,
+    convertTo(1/255) + flow of consecutive pairs + fused centroid rows out."""
+    import sharding
+    import synth
+    v = synth.video(4, 160, 240, seed=21)
+    fr = np.clip(np.rint(v * 255), 0, 255).astype(np.uint8)
+    U, V, rows = sharding.stream_flow(dev(torch, fr), gpu_ctx, 3, 15, thresh=0.5)
+    assert U.shape == (3, 160, 240) and rows.shape == (3, 3)
+    for p in range(3):
+        a, b = oracle.u8_to_f64(fr[p]), oracle.u8_to_f64(fr[p + 1])
+        uo, vo = oracle.coarse_to_fine(a, b, 3, 15)
+        assert np.abs(host(U[p]) - uo).max() <= TOL and np.abs(host(V[p]) - vo).max() <= TOL
+        c, sx, sy = oracle.flow_centroid(host(U[p]), host(V[p]), 0.5)
+        assert tuple(host(rows[p])) == (float(c), sx, sy)
