@@ -57,12 +57,14 @@ __device__ __forceinline__ UpSel1 make_upsel1(int x, int Wc)
 }
 __device__ __forceinline__ double pyrup_h1(const double *c, const UpSel1 &s)
 {
-    const double B = c[s.jc], C = c[s.jp];
-    if (s.odd) return (B + (s.dup ? B : C)) * 4;
-    const double A = c[s.jm];
+    // branch-free: both parities are evaluated, the lane's own is selected (odd/even lanes alternate,
+    // so a branch would execute both sides anyway)
+    const double A = c[s.jm], B = c[s.jc], C = c[s.jp];
     const double A1 = s.keepA ? A : 0.0;
     const double C2 = s.cmode == 2 ? C * 2 : (s.cmode == 1 ? C : 0.0);
-    return (A1 + B * s.mB) + C2;
+    const double ev = (A1 + B * s.mB) + C2;
+    const double od = (B + (s.dup ? B : C)) * 4;
+    return s.odd ? od : ev;
 }
 
 template <int WIN, int TX, bool HAS_UP>
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
     const int x = (int)blockIdx.x * XO - R + t;
     const int y0 = blockIdx.y * a.th;
     const int y1 = min(y0 + a.th, H);
-    const long long pitch = a.i1.pitch;
+    const int pitch = (int)a.i1.pitch;       // one plane is < 2^31 elements (checked on the host)
     const bool col_in = x >= 0 && x < W;
     const int xc = min(max(x, 0), W - 1);
     const int xl = r101(xc - 1, W);
@@ -104,23 +106,29 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
     double pre[5] = {0, 0, 0, 0, 0};
 
     // previous row (pa*, pb*) and prefetched current row (ca*, cb*): [0] = left tap, [1] = own
-    const int yfirst = max(yy0, 0);
-    long long ro = (long long)r101(yfirst - 1, H) * pitch;
+    int ro = r101(yy0 - 1, H) * pitch;
     double pa0 = I1l[ro], pa1 = I1c[ro], pb0 = I2l[ro], pb1 = I2c[ro];
-    ro = (long long)yfirst * pitch;
+    ro = r101(yy0, H) * pitch;
     double ca0 = I1l[ro], ca1 = I1c[ro], cb0 = I2l[ro], cb1 = I2c[ro];
 
     [[maybe_unused]] UpSel1 us{};
     [[maybe_unused]] double hu[3] = {0, 0, 0}, hv[3] = {0, 0, 0};   // carried coarse rows s(i-1),s(i),s(i+1)
     [[maybe_unused]] const int Hc = H >> 1;
     [[maybe_unused]] const double *CU = nullptr, *CV = nullptr;
-    [[maybe_unused]] int up_i = -1000000;
+    [[maybe_unused]] const int cpu = (int)a.cu.pitch, cpv = (int)a.cv.pitch;
+    auto up_srow = [&](int k) { return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };
     if (HAS_UP) {
         us = make_upsel1(xc, W >> 1);
         CU = a.cu.at(pair);
         CV = a.cv.at(pair);
+        const int i0 = y0 >> 1;                                 // slots of the first output row
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int sr = up_srow(i0 - 1 + s);
+            hu[s] = pyrup_h1(CU + sr * cpu, us);
+            hv[s] = pyrup_h1(CV + sr * cpv, us);
+        }
     }
-    auto up_srow = [&](int k) { return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };
 
     // One marched row at chunk position K (compile-time): the chunk loop below is unrolled WIN
     // times so that every ring access is a plain register (no dispatch, no copies).
@@ -128,26 +136,27 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         constexpr int K = decltype(kc)::value;
         const int bsel = i & 1;
         const int yy = yy0 + i;
-        double p[5] = {0, 0, 0, 0, 0};
-        if (yy >= 0 && yy < H) {
-            double na0 = 0, na1 = 0, nb0 = 0, nb1 = 0;
-            if (yy + 1 < H) {                                   // prefetch the next row
-                const long long rn = (long long)(yy + 1) * pitch;
-                na0 = I1l[rn]; na1 = I1c[rn]; nb0 = I2l[rn]; nb1 = I2c[rn];
-            }
-            lk_products(pa0, pa1, ca0, ca1, pb0, pb1, cb0, cb1, p);
-            if (!col_in) {
+        const bool row_in = yy >= 0 && yy < H;
+        // prefetch the next image row (clamped, unconditional); consumed by the rotate below, after
+        // the window sums, so that its latency hides behind this row's work
+        // apron rows carry the reflected row (at yy = 0 the "previous" row is row 1 = r101(-1));
+        // one reflection suffices unless the image is shorter than the apron
+        int rr = yy + 1;
+        rr = rr < 0 ? -rr : rr;
+        rr = rr >= H ? 2 * H - 2 - rr : rr;
+        if (H <= R + 1) rr = r101(yy + 1, H);
+        const int rn = rr * pitch;
+        const double na0 = I1l[rn], na1 = I1c[rn], nb0 = I2l[rn], nb1 = I2c[rn];
+        double p[5];
+        lk_products(pa0, pa1, ca0, ca1, pb0, pb1, cb0, cb1, p);
+        const bool keep = row_in && col_in;
 #pragma unroll
-                for (int f = 0; f < 5; ++f) p[f] = 0.0;
-            }
-            pa0 = ca0; pa1 = ca1; pb0 = cb0; pb1 = cb1;
-            ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
-        }
+        for (int f = 0; f < 5; ++f) p[f] = keep ? p[f] : 0.0;
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
             const double q = p[f] + dpp_swap1(p[f]);
             s_p[bsel][f][PP + t] = p[f];
-            if ((t & 1) == 0) s_q[bsel][f][PQ + (t >> 1)] = q;
+            s_q[bsel][f][PQ + (t >> 1)] = q;                    // both lanes of a pair store the same value
         }
         __syncthreads();
 
@@ -170,6 +179,10 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
                 for (int f = 0; f < 5; ++f) ring[q][f] += ring[q + 1][f];
         }
 
+        // rotate: the only wait for the prefetch
+        pa0 = ca0; pa1 = ca1; pb0 = cb0; pb1 = cb1;
+        ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
+
         const int y = yy - R;
         if (i >= 2 * R && is_out) {
             double u = 0.0, v = 0.0;
@@ -181,25 +194,20 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
 #pragma unroll
                     for (int f = 0; f < 5; ++f) S[f] = pc[f] * (double)(WIN * WIN);
                 }
-                lk_solve(S, u, v);
+                const double det = S[0] * S[1] - S[2] * S[2];
+                const double un = S[2] * S[4] - S[1] * S[3];
+                const double vn = S[3] * S[2] - S[0] * S[4];
+                const bool nz = det != 0.0;                    // cv::divide: x/0 -> 0
+                const double qu = un / det, qv = vn / det;
+                u = nz ? qu : 0.0;
+                v = nz ? qv : 0.0;
             }
             if (HAS_UP) {
-                const int ci = y >> 1;
-                if (ci != up_i) {                               // every second fine row
-                    if (ci == up_i + 1) {
-                        hu[0] = hu[1]; hu[1] = hu[2]; hv[0] = hv[1]; hv[1] = hv[2];
-                        const int sr = up_srow(ci + 1);
-                        hu[2] = pyrup_h1(CU + (long long)sr * a.cu.pitch, us);
-                        hv[2] = pyrup_h1(CV + (long long)sr * a.cv.pitch, us);
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < 3; ++s) {
-                            const int sr = up_srow(ci - 1 + s);
-                            hu[s] = pyrup_h1(CU + (long long)sr * a.cu.pitch, us);
-                            hv[s] = pyrup_h1(CV + (long long)sr * a.cv.pitch, us);
-                        }
-                    }
-                    up_i = ci;
+                if ((y & 1) == 0 && y > y0) {                   // wave-uniform: new coarse row every 2nd row
+                    hu[0] = hu[1]; hu[1] = hu[2]; hv[0] = hv[1]; hv[1] = hv[2];
+                    const int sr = up_srow((y >> 1) + 1);
+                    hu[2] = pyrup_h1(CU + sr * cpu, us);
+                    hv[2] = pyrup_h1(CV + sr * cpv, us);
                 }
                 if (y & 1) {
                     u += ((hu[1] + hu[2]) * 4) * (1.0 / 64);
@@ -209,8 +217,8 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
                     v += (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);
                 }
             }
-            a.u.at(pair)[(long long)y * a.u.pitch + x] = u;
-            a.v.at(pair)[(long long)y * a.v.pitch + x] = v;
+            a.u.at(pair)[y * (int)a.u.pitch + x] = u;
+            a.v.at(pair)[y * (int)a.v.pitch + x] = v;
         }
     };
 

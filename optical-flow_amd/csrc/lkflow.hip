@@ -253,7 +253,10 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
         return LKFLOW_OK;
     }
     if (ctx->impl == 0) {
-        int rc = launch_lk3<256>(ctx, a, has_up, pairs, win, s);
+        #ifndef LK3_TX
+#define LK3_TX 256
+#endif
+        int rc = launch_lk3<LK3_TX>(ctx, a, has_up, pairs, win, s);
         if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
         return LKFLOW_OK;
