@@ -132,24 +132,37 @@ __device__ __forceinline__ int sat_short(int v)
     return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
 }
 
+// cvRound(t) for a FLOAT argument (the map coordinate * 32): float -> double is exact, so rounding the
+// float half-to-even gives the same integer as cv_round((double)t), at 32-bit instruction cost.
+__device__ __forceinline__ int cv_round_f(float t)
+{
+    if (!(fabsf(t) < 2147483648.0f)) return INT_MIN;   // NaN / out of range -> 0x80000000
+    return __float2int_rn(t);
+}
+
 // cv::remap INTER_LINEAR / BORDER_CONSTANT(0) sample of src at float map coordinate (mx,my)
 // (OpenCV 2.4 imgwarp.cpp: 1/32-pixel fixed point, float weight table, fp64 blend).
 __device__ __forceinline__ double remap_bilinear(const double *src, long long pitch, int H, int W,
                                                  float mx, float my)
 {
-    const int sx = cv_round((double)(mx * 32.0f));
-    const int sy = cv_round((double)(my * 32.0f));
+    const int sx = cv_round_f(mx * 32.0f);
+    const int sy = cv_round_f(my * 32.0f);
     const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
     const float a = (float)(sx & 31) * (1.0f / 32), b = (float)(sy & 31) * (1.0f / 32);
     const float w0 = (1.0f - b) * (1.0f - a), w1 = (1.0f - b) * a, w2 = b * (1.0f - a), w3 = b * a;
-    const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W;
-    const bool y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
     const double *r0 = src + (long long)iy * pitch + ix;
     const double *r1 = r0 + pitch;
-    const double v0 = (y0 && x0) ? r0[0] : 0.0;
-    const double v1 = (y0 && x1) ? r0[1] : 0.0;
-    const double v2 = (y1 && x0) ? r1[0] : 0.0;
-    const double v3 = (y1 && x1) ? r1[1] : 0.0;
+    double v0, v1, v2, v3;
+    if ((unsigned)ix < (unsigned)(W - 1) && (unsigned)iy < (unsigned)(H - 1)) {   // all four taps inside
+        v0 = r0[0]; v1 = r0[1]; v2 = r1[0]; v3 = r1[1];
+    } else {
+        const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W;
+        const bool y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
+        v0 = (y0 && x0) ? r0[0] : 0.0;
+        v1 = (y0 && x1) ? r0[1] : 0.0;
+        v2 = (y1 && x0) ? r1[0] : 0.0;
+        v3 = (y1 && x1) ? r1[1] : 0.0;
+    }
     return v0 * (double)w0 + v1 * (double)w1 + v2 * (double)w2 + v3 * (double)w3;
 }
 

@@ -49,35 +49,46 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
     const int bx = tile % a.gx; tile /= a.gx;
     const int by = tile % a.gy;
     const int plane = tile / a.gy;
+    const int wrow = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const int xo = (bx * 64 + (threadIdx.x & 63)) * 2;      // first output column of the quad
-    const int yo = (by * 4 + (threadIdx.x >> 6)) * 2;       // first output row
-    if (xo >= a.Wd || yo >= a.Hd) return;
+    const int yo = (by * 4 + wrow) * 2;                     // first output row (uniform per wave)
+    if (yo >= a.Hd) return;
     const int H = a.H, W = a.W;
     const double *s = a.src.at(plane);
     const int pitch = (int)a.src.pitch;
     const int xs = 2 * xo - 2;                              // first source column (even)
-    const bool fast = a.vec_src && xs >= 0 && xs + 6 < W;
-    int cx[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) cx[k] = r101(xs + k, W);
+    const int ys = 2 * yo - 2;                              // first source row
+    // interior tiles (the vast majority) need no border logic at all: decided per wave
+    const bool rows_in = ys >= 0 && ys + 6 < H;
+    const int xs_lo = 2 * (bx * 64) * 2 - 2, xs_hi = 2 * (bx * 64 + 63) * 2 - 2 + 6;
+    const bool wave_fast = a.vec_src && rows_in && xs_lo >= 0 && xs_hi < W;
 
     double h0[7], h1[7];                                    // horizontal results of the 7 source rows
+    if (wave_fast) {
+        const double *r = s + ys * pitch + xs;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const double *r = s + r101(2 * yo - 2 + k, H) * pitch;
-        double v[7];
-        if (fast) {
-            const double2 p0 = *reinterpret_cast<const double2 *>(r + xs);
-            const double2 p1 = *reinterpret_cast<const double2 *>(r + xs + 2);
-            const double2 p2 = *reinterpret_cast<const double2 *>(r + xs + 4);
-            v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y;
-            v[6] = r[xs + 6];
-        } else {
+        for (int k = 0; k < 7; ++k, r += pitch) {
+            const double2 p0 = *reinterpret_cast<const double2 *>(r);
+            const double2 p1 = *reinterpret_cast<const double2 *>(r + 2);
+            const double2 p2 = *reinterpret_cast<const double2 *>(r + 4);
+            const double v6 = r[6];
+            h0[k] = p1.x * 6 + (p0.y + p1.y) * 4 + p0.x + p2.x;
+            h1[k] = p2.x * 6 + (p1.y + p2.y) * 4 + p1.x + v6;
+        }
+    } else {
+        if (xo >= a.Wd) return;
+        int cx[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) cx[k] = r101(xs + k, W);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double *r = s + r101(ys + k, H) * pitch;
+            double v[7];
 #pragma unroll
             for (int j = 0; j < 7; ++j) v[j] = r[cx[j]];
+            h0[k] = v[2] * 6 + (v[1] + v[3]) * 4 + v[0] + v[4];
+            h1[k] = v[4] * 6 + (v[3] + v[5]) * 4 + v[2] + v[6];
         }
-        h0[k] = v[2] * 6 + (v[1] + v[3]) * 4 + v[0] + v[4];
-        h1[k] = v[4] * 6 + (v[3] + v[5]) * 4 + v[2] + v[6];
     }
     const double o00 = (h0[2] * 6 + (h0[1] + h0[3]) * 4 + h0[0] + h0[4]) * (1.0 / 256);
     const double o01 = (h1[2] * 6 + (h1[1] + h1[3]) * 4 + h1[0] + h1[4]) * (1.0 / 256);
@@ -85,6 +96,7 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
     const double o11 = (h1[4] * 6 + (h1[3] + h1[5]) * 4 + h1[2] + h1[6]) * (1.0 / 256);
     double *d = a.dst.at(plane) + yo * (int)a.dst.pitch + xo;
     const bool two_c = xo + 1 < a.Wd, two_r = yo + 1 < a.Hd;
+    if (xo >= a.Wd) return;
     if (two_c && a.vec_dst) {
         *reinterpret_cast<double2 *>(d) = make_double2(o00, o01);
         if (two_r) *reinterpret_cast<double2 *>(d + a.dst.pitch) = make_double2(o10, o11);

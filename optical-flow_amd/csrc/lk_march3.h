@@ -55,11 +55,15 @@ __device__ __forceinline__ UpSel1 make_upsel1(int x, int Wc)
     s.dup = single || right;
     return s;
 }
+__device__ __forceinline__ double pyrup_h1v(double A, double B, double C, const UpSel1 &s);
 __device__ __forceinline__ double pyrup_h1(const double *c, const UpSel1 &s)
+{
+    return pyrup_h1v(c[s.jm], c[s.jc], c[s.jp], s);
+}
+__device__ __forceinline__ double pyrup_h1v(double A, double B, double C, const UpSel1 &s)
 {
     // branch-free: both parities are evaluated, the lane's own is selected (odd/even lanes alternate,
     // so a branch would execute both sides anyway)
-    const double A = c[s.jm], B = c[s.jc], C = c[s.jp];
     const double A1 = s.keepA ? A : 0.0;
     const double C2 = s.cmode == 2 ? C * 2 : (s.cmode == 1 ? C : 0.0);
     const double ev = (A1 + B * s.mB) + C2;
@@ -147,11 +151,29 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         if (H <= R + 1) rr = r101(yy + 1, H);
         const int rn = rr * pitch;
         const double na0 = I1l[rn], na1 = I1c[rn], nb0 = I2l[rn], nb1 = I2c[rn];
+        const int y = yy - R;                                   // output row of this iteration
+        const bool out_row = i >= 2 * R;
+        // the NEXT coarse row of the "+= pyrUp" term is fetched during odd output rows (slot 0 of the
+        // carried rows is dead there) and turned into the new slot in this row's epilogue
+        [[maybe_unused]] double uA = 0, uB = 0, uC = 0, vA = 0, vB = 0, vC = 0;
+        const bool up_pref = HAS_UP && out_row && (y & 1) != 0;
+        if (up_pref) {
+            const int sr = up_srow(((y + 1) >> 1) + 1);
+            const double *ru = CU + sr * cpu, *rv = CV + sr * cpv;
+            uA = ru[us.jm]; uB = ru[us.jc]; uC = ru[us.jp];
+            vA = rv[us.jm]; vB = rv[us.jc]; vC = rv[us.jp];
+        }
         double p[5];
-        lk_products(pa0, pa1, ca0, ca1, pb0, pb1, cb0, cb1, p);
-        const bool keep = row_in && col_in;
-#pragma unroll
-        for (int f = 0; f < 5; ++f) p[f] = keep ? p[f] : 0.0;
+        {
+            // products; rows/columns outside the image contribute 0: zeroing fx and fy zeroes all five
+            const bool keep = row_in && col_in;
+            double fx = f2d_x(pa0, pa1, ca0, ca1) + f2d_x(pb0, pb1, cb0, cb1);
+            double fy = f2d_y(pa0, pa1, ca0, ca1) + f2d_y(pb0, pb1, cb0, cb1);
+            const double ft = f2d_neg(pa0, pa1, ca0, ca1) + f2d_pos(pb0, pb1, cb0, cb1);
+            fx = keep ? fx : 0.0;
+            fy = keep ? fy : 0.0;
+            p[0] = fx * fx; p[1] = fy * fy; p[2] = fx * fy; p[3] = fx * ft; p[4] = fy * ft;
+        }
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
             const double q = p[f] + dpp_swap1(p[f]);
@@ -183,8 +205,7 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         pa0 = ca0; pa1 = ca1; pb0 = cb0; pb1 = cb1;
         ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
 
-        const int y = yy - R;
-        if (i >= 2 * R && is_out) {
+        if (out_row && is_out) {
             double u = 0.0, v = 0.0;
             if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
                 const bool clipped = (y - R < 0) || (y + R > H - 1) || (x - R < 0) || (x + R > W - 1);
@@ -203,15 +224,16 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
                 v = nz ? qv : 0.0;
             }
             if (HAS_UP) {
-                if ((y & 1) == 0 && y > y0) {                   // wave-uniform: new coarse row every 2nd row
-                    hu[0] = hu[1]; hu[1] = hu[2]; hv[0] = hv[1]; hv[1] = hv[2];
-                    const int sr = up_srow((y >> 1) + 1);
-                    hu[2] = pyrup_h1(CU + sr * cpu, us);
-                    hv[2] = pyrup_h1(CV + sr * cpv, us);
+                if ((y & 1) == 0 && y > y0) {                   // wave-uniform: rotate in the row fetched last time
+                    const double nu = hu[0], nv = hv[0];
+                    hu[0] = hu[1]; hu[1] = hu[2]; hu[2] = nu;
+                    hv[0] = hv[1]; hv[1] = hv[2]; hv[2] = nv;
                 }
                 if (y & 1) {
                     u += ((hu[1] + hu[2]) * 4) * (1.0 / 64);
                     v += ((hv[1] + hv[2]) * 4) * (1.0 / 64);
+                    hu[0] = pyrup_h1v(uA, uB, uC, us);          // next coarse row, used from row y+1 on
+                    hv[0] = pyrup_h1v(vA, vB, vC, us);
                 } else {
                     u += (hu[0] + hu[1] * 6 + hu[2]) * (1.0 / 64);
                     v += (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);
