@@ -28,19 +28,39 @@ __device__ __forceinline__ unsigned xcd_tile_id(unsigned lin, unsigned n)
 }
 
 // ------------------------------------------------------------------------------------------------
-// cv::pyrDown.  One thread = a 2x2 quad of OUTPUT pixels = a 7x7 source patch read as 16-byte
-// pairs (interior) or reflect-101 clamped scalars (border); horizontal [1 4 6 4 1] per source row,
-// then vertical, then * 1/256 -- same expression order as OpenCV 2.4 pyrDown_.
-// Block = 64 x 4 threads = a 128 x 8 output tile; 1-D grid over (planes, tile rows, tile cols).
+// cv::pyrDown, row-marching -- same expression order as OpenCV 2.4 pyrDown_:
+//   row[x] = s[2x]*6 + (s[2x-1] + s[2x+1])*4 + s[2x-2] + s[2x+2]         (horizontal, per source row)
+//   dst[x] = (row2*6 + (row1 + row3)*4 + row0 + row4) * (1/256)            (vertical)
+// Lane l of a wave owns the source column PAIR (2*ox, 2*ox+1) of output column ox = ox_w + l - 1 and
+// loads it with one 16-byte access: a wave reads 1 KiB contiguous per source row, every line exactly
+// once.  The other three horizontal taps come from the neighbouring lanes through DPP wave shifts
+// (lanes 0 and 63 are halo lanes, so a wave yields 62 columns); the vertical pass keeps the last
+// five horizontal results in registers while the wave marches down its strip of output rows.
+// No LDS, no barriers, ~30 VGPRs.  Block = 4 waves side by side (248 output columns).
 // ------------------------------------------------------------------------------------------------
 struct PyrDownArgs {
     CPlanes src;
     Planes dst;
     int H, W, Hd, Wd;
     int gx, gy;        // tiles per plane
+    int th;            // output rows per block
     int vec_src;       // src: 16-byte aligned base, even pitch/plane -> double2 loads
-    int vec_dst;
 };
+
+constexpr int PD_WCOLS = 62;                          // valid output columns per wave
+
+__device__ __forceinline__ double dpp_wave_shr1(double v)      // lane l <- lane l-1
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_wave_shl1(double v)      // lane l <- lane l+1
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 
 __global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
 {
@@ -49,64 +69,57 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
     const int bx = tile % a.gx; tile /= a.gx;
     const int by = tile % a.gy;
     const int plane = tile / a.gy;
-    const int wrow = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
-    const int xo = (bx * 64 + (threadIdx.x & 63)) * 2;      // first output column of the quad
-    const int yo = (by * 4 + wrow) * 2;                     // first output row (uniform per wave)
-    if (yo >= a.Hd) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int H = a.H, W = a.W;
+    const int ox = (bx * 4 + wave) * PD_WCOLS + lane - 1;   // output column of this lane (halo: -1 / +62)
+    const int oy0 = by * a.th, oy1 = min(oy0 + a.th, a.Hd);
+    if ((bx * 4 + wave) * PD_WCOLS >= a.Wd) return;         // whole wave outside (wave-uniform)
     const double *s = a.src.at(plane);
     const int pitch = (int)a.src.pitch;
-    const int xs = 2 * xo - 2;                              // first source column (even)
-    const int ys = 2 * yo - 2;                              // first source row
-    // interior tiles (the vast majority) need no border logic at all: decided per wave
-    const bool rows_in = ys >= 0 && ys + 6 < H;
-    const int xs_lo = 2 * (bx * 64) * 2 - 2, xs_hi = 2 * (bx * 64 + 63) * 2 - 2 + 6;
-    const bool wave_fast = a.vec_src && rows_in && xs_lo >= 0 && xs_hi < W;
+    const int c0 = 2 * ox;                                  // source columns c0, c0+1
+    const bool vec = a.vec_src && c0 >= 0 && c0 + 1 < W;
+    const int r0c = r101(c0, W), r1c = r101(c0 + 1, W);
 
-    double h0[7], h1[7];                                    // horizontal results of the 7 source rows
-    if (wave_fast) {
-        const double *r = s + ys * pitch + xs;
-#pragma unroll
-        for (int k = 0; k < 7; ++k, r += pitch) {
-            const double2 p0 = *reinterpret_cast<const double2 *>(r);
-            const double2 p1 = *reinterpret_cast<const double2 *>(r + 2);
-            const double2 p2 = *reinterpret_cast<const double2 *>(r + 4);
-            const double v6 = r[6];
-            h0[k] = p1.x * 6 + (p0.y + p1.y) * 4 + p0.x + p2.x;
-            h1[k] = p2.x * 6 + (p1.y + p2.y) * 4 + p1.x + v6;
+    // one source row: 16-byte load of this lane's column pair (issued early) ...
+    auto ld = [&](int sy, double &cx, double &cy) __attribute__((always_inline)) {
+        const double *r = s + r101(sy, H) * pitch;          // row index is wave-uniform
+        if (vec) {
+            const double2 p = *reinterpret_cast<const double2 *>(r + c0);
+            cx = p.x; cy = p.y;
+        } else {
+            cx = r[r0c]; cy = r[r1c];
         }
-    } else {
-        if (xo >= a.Wd) return;
-        int cx[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) cx[k] = r101(xs + k, W);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const double *r = s + r101(ys + k, H) * pitch;
-            double v[7];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) v[j] = r[cx[j]];
-            h0[k] = v[2] * 6 + (v[1] + v[3]) * 4 + v[0] + v[4];
-            h1[k] = v[4] * 6 + (v[3] + v[5]) * 4 + v[2] + v[6];
-        }
+    };
+    // ... and its horizontal result for this lane's output column (neighbour taps by DPP wave shifts)
+    auto hf = [&](double cx, double cy) __attribute__((always_inline)) -> double {
+        const double lx = dpp_wave_shr1(cx), ly = dpp_wave_shr1(cy), rx = dpp_wave_shl1(cx);
+        return cx * 6 + (ly + cy) * 4 + lx + rx;
+    };
+
+    double ax, ay, bx2, by2, cx2, cy2;
+    ld(2 * oy0 - 2, ax, ay); ld(2 * oy0 - 1, bx2, by2); ld(2 * oy0, cx2, cy2);
+    double h0 = hf(ax, ay), h1 = hf(bx2, by2), h2 = hf(cx2, cy2);
+    const bool out_lane = lane >= 1 && lane <= PD_WCOLS && ox < a.Wd;
+    const int dp = (int)a.dst.pitch;
+    double *d = a.dst.at(plane) + oy0 * dp + ox;
+    // two output rows per iteration: four independent 16-byte loads in flight per lane
+    int oy = oy0;
+    for (; oy + 1 < oy1; oy += 2) {
+        double p3x, p3y, p4x, p4y, p5x, p5y, p6x, p6y;
+        ld(2 * oy + 1, p3x, p3y); ld(2 * oy + 2, p4x, p4y); ld(2 * oy + 3, p5x, p5y); ld(2 * oy + 4, p6x, p6y);
+        const double h3 = hf(p3x, p3y), h4 = hf(p4x, p4y), h5 = hf(p5x, p5y), h6 = hf(p6x, p6y);
+        const double o0 = (h2 * 6 + (h1 + h3) * 4 + h0 + h4) * (1.0 / 256);
+        const double o1 = (h4 * 6 + (h3 + h5) * 4 + h2 + h6) * (1.0 / 256);
+        if (out_lane) { d[0] = o0; d[dp] = o1; }
+        d += 2 * dp;
+        h0 = h4; h1 = h5; h2 = h6;
     }
-    const double o00 = (h0[2] * 6 + (h0[1] + h0[3]) * 4 + h0[0] + h0[4]) * (1.0 / 256);
-    const double o01 = (h1[2] * 6 + (h1[1] + h1[3]) * 4 + h1[0] + h1[4]) * (1.0 / 256);
-    const double o10 = (h0[4] * 6 + (h0[3] + h0[5]) * 4 + h0[2] + h0[6]) * (1.0 / 256);
-    const double o11 = (h1[4] * 6 + (h1[3] + h1[5]) * 4 + h1[2] + h1[6]) * (1.0 / 256);
-    double *d = a.dst.at(plane) + yo * (int)a.dst.pitch + xo;
-    const bool two_c = xo + 1 < a.Wd, two_r = yo + 1 < a.Hd;
-    if (xo >= a.Wd) return;
-    if (two_c && a.vec_dst) {
-        *reinterpret_cast<double2 *>(d) = make_double2(o00, o01);
-        if (two_r) *reinterpret_cast<double2 *>(d + a.dst.pitch) = make_double2(o10, o11);
-    } else {
-        d[0] = o00;
-        if (two_c) d[1] = o01;
-        if (two_r) {
-            d[a.dst.pitch] = o10;
-            if (two_c) d[a.dst.pitch + 1] = o11;
-        }
+    if (oy < oy1) {
+        double p3x, p3y, p4x, p4y;
+        ld(2 * oy + 1, p3x, p3y); ld(2 * oy + 2, p4x, p4y);
+        const double h3 = hf(p3x, p3y), h4 = hf(p4x, p4y);
+        if (out_lane) d[0] = (h2 * 6 + (h1 + h3) * 4 + h0 + h4) * (1.0 / 256);
     }
 }
 
@@ -126,43 +139,90 @@ __global__ __launch_bounds__(256) void pyrup_kernel(CPlanes src, int Hc, int Wc,
 // ------------------------------------------------------------------------------------------------
 // Warp of one pyramid level: up-sample the coarse flow, build the float map, remap both images.
 // ParallelVideoPyr.cpp:646-703.  H, W are the fine level's size (= 2*Hc, 2*Wc, both even).
-// One thread = a 2x2 quad of fine pixels, which shares one 3x3 coarse neighbourhood per flow
-// plane for cv::pyrUp (branch-free border handling, same roundings as pyrup_at()); 32 independent
-// gather loads per thread keep the memory pipe busy; 16-byte stores.
-// Block = 64 x 4 threads = a 128 x 8 pixel tile; XCD-aware 1-D grid.
+//
+// What bounds this kernel is the vector-memory front end (L1 line look-ups per gather instruction),
+// so lanes map to CONSECUTIVE columns -- a gather instruction then touches 4-5 full 128-byte lines
+// instead of 8 half-used ones -- and the two horizontal taps of a row are fetched as one 16-byte
+// load.  One thread = a 1 x 4 column strip (x, y..y+3), y a multiple of 4: the strip spans two coarse
+// rows, so cv::pyrUp needs 4 coarse rows x 3 columns per flow plane (branch-free borders, same
+// roundings as pyrup_at()).  Block = 4 waves = 64 columns x 16 rows; XCD-aware 1-D grid.
 // ------------------------------------------------------------------------------------------------
 struct WarpArgs {
     CPlanes img1, img2, cu, cv;
     Planes out1, out2;
     int H, W;
     int gx, gy;
-    int vec_out;
 };
 
-__device__ __forceinline__ void pyrup_quad(const double *c, int cp, int Hc, int Wc, int i, int j,
-                                           double (&o)[2][2])
+// the four fine rows y0..y0+3 (y0 = 4m) of cv::pyrUp at fine column x
+__device__ __forceinline__ void pyrup_strip4(const double *c, int cp, int Hc, int Wc, int y0, int x,
+                                             double (&o)[4])
 {
+    const int j = x >> 1;
     const int jm = j > 0 ? j - 1 : 0, jp = j < Wc - 1 ? j + 1 : Wc - 1;
-    const bool single = Wc == 1, left = j == 0, right = j == Wc - 1;
+    const bool single = Wc == 1, left = j == 0, right = j == Wc - 1, odd = (x & 1) != 0;
     const double mB = single ? 8.0 : (right ? 7.0 : 6.0);
     const double wA = (single || left) ? 0.0 : 1.0;
     const double wC = (single || right) ? 0.0 : (left ? 2.0 : 1.0);
     const bool dup = single || right;
-    const int s0 = i - 1 < 0 ? min(1, Hc - 1) : i - 1;      // r101(2k, 2Hc)/2
-    const int s2 = i + 1 > Hc - 1 ? Hc - 1 : i + 1;
-    const int srow[3] = {s0, i, s2};
-    double ev[3], od[3];
+    const int i = y0 >> 1;                                  // coarse rows i-1 .. i+2 (clamped like r101(2k,2Hc)/2)
+    double h[4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double *r = c + srow[k] * cp;
+    for (int k = 0; k < 4; ++k) {
+        const int kk = i - 1 + k;
+        const int sr = kk < 0 ? min(1, Hc - 1) : (kk > Hc - 1 ? Hc - 1 : kk);
+        const double *r = c + sr * cp;
         const double A = r[jm], B = r[j], C = r[jp];
-        ev[k] = (A * wA + B * mB) + C * wC;
-        od[k] = (B + (dup ? B : C)) * 4;
+        const double ev = (A * wA + B * mB) + C * wC;
+        const double od = (B + (dup ? B : C)) * 4;
+        h[k] = odd ? od : ev;
     }
-    o[0][0] = (ev[0] + ev[1] * 6 + ev[2]) * (1.0 / 64);
-    o[0][1] = (od[0] + od[1] * 6 + od[2]) * (1.0 / 64);
-    o[1][0] = ((ev[1] + ev[2]) * 4) * (1.0 / 64);
-    o[1][1] = ((od[1] + od[2]) * 4) * (1.0 / 64);
+    o[0] = (h[0] + h[1] * 6 + h[2]) * (1.0 / 64);           // y0     = 2i
+    o[1] = ((h[1] + h[2]) * 4) * (1.0 / 64);                // y0 + 1
+    o[2] = (h[1] + h[2] * 6 + h[3]) * (1.0 / 64);           // y0 + 2 = 2(i+1)
+    o[3] = ((h[2] + h[3]) * 4) * (1.0 / 64);                // y0 + 3
+}
+
+// remap_bilinear() with the two horizontal taps of each row fetched as one 16-byte load
+__device__ __forceinline__ double remap_bilinear_v2(const double *src, int pitch, int H, int W, float mx,
+                                                    float my)
+{
+    const int sx = cv_round_f(mx * 32.0f);
+    const int sy = cv_round_f(my * 32.0f);
+    const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
+    const float a = (float)(sx & 31) * (1.0f / 32), b = (float)(sy & 31) * (1.0f / 32);
+    const float w0 = (1.0f - b) * (1.0f - a), w1 = (1.0f - b) * a, w2 = b * (1.0f - a), w3 = b * a;
+    double v0, v1, v2, v3;
+#if defined(LKW_TIMING_NOSLOW)   /* timing experiment only: wrong at the image border */
+    {
+        const int cx = min(max(ix, 0), W - 2), cy = min(max(iy, 0), H - 2);
+        const double *r0 = src + cy * pitch + cx;
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        const d2u t0 = *reinterpret_cast<const d2u *>(r0);
+        const d2u t1 = *reinterpret_cast<const d2u *>(r0 + pitch);
+        v0 = t0.x; v1 = t0.y; v2 = t1.x; v3 = t1.y;
+    }
+    if (false) {
+#else
+    if ((unsigned)ix < (unsigned)(W - 1) && (unsigned)iy < (unsigned)(H - 1)) {   // all four taps inside
+#endif
+        const double *r0 = src + iy * pitch + ix;
+        // 8-byte aligned 16-byte loads: dword-aligned multi-dword global loads are legal on gfx9
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        const d2u t0 = *reinterpret_cast<const d2u *>(r0);
+        const d2u t1 = *reinterpret_cast<const d2u *>(r0 + pitch);
+        v0 = t0.x; v1 = t0.y; v2 = t1.x; v3 = t1.y;
+    } else {
+        const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W;
+        const bool y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
+        const double *r0 = src + (long long)iy * pitch + ix;
+        const double *r1 = r0 + pitch;
+        v0 = (y0 && x0) ? r0[0] : 0.0;
+        v1 = (y0 && x1) ? r0[1] : 0.0;
+        v2 = (y1 && x0) ? r1[0] : 0.0;
+        v3 = (y1 && x1) ? r1[1] : 0.0;
+    }
+    return v0 * (double)w0 + v1 * (double)w1 + v2 * (double)w2 + v3 * (double)w3;
 }
 
 __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
@@ -172,31 +232,34 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     const int bx = tile % a.gx; tile /= a.gx;
     const int by = tile % a.gy;
     const int p = tile / a.gy;
-    const int x = (bx * 64 + (threadIdx.x & 63)) * 2;
-    const int y = (by * 4 + (threadIdx.x >> 6)) * 2;
+    const int wrow = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = bx * 64 + (threadIdx.x & 63);
+    const int y0 = (by * 4 + wrow) * 4;
     const int H = a.H, W = a.W;
-    if (x >= W || y >= H) return;
-    double upu[2][2], upv[2][2];
-    pyrup_quad(a.cu.at(p), (int)a.cu.pitch, H >> 1, W >> 1, y >> 1, x >> 1, upu);
-    pyrup_quad(a.cv.at(p), (int)a.cv.pitch, H >> 1, W >> 1, y >> 1, x >> 1, upv);
+    if (x >= W || y0 >= H) return;
+    double upu[4], upv[4];
+#if defined(LKW_TIMING_NOUP)     /* timing experiment only */
+    for (int k = 0; k < 4; ++k) { upu[k] = 1.5 + 1e-3 * x; upv[k] = -0.75 + 1e-3 * y0; }
+#else
+    pyrup_strip4(a.cu.at(p), (int)a.cu.pitch, H >> 1, W >> 1, y0, x, upu);
+    pyrup_strip4(a.cv.at(p), (int)a.cv.pitch, H >> 1, W >> 1, y0, x, upv);
+#endif
     const double *I1 = a.img1.at(p), *I2 = a.img2.at(p);
-    const long long ip = a.img1.pitch;
-    double w1[2][2], w2[2][2];
+    const int ip = (int)a.img1.pitch;
+    double *o1 = a.out1.at(p) + y0 * (int)a.out1.pitch + x;
+    double *o2 = a.out2.at(p) + y0 * (int)a.out2.pitch + x;
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx)
-            warp_pair_at(I1, I2, ip, H, W, y + dy, x + dx, upu[dy][dx], upv[dy][dx], w1[dy][dx], w2[dy][dx]);
-    double *o1 = a.out1.at(p) + y * (int)a.out1.pitch + x;
-    double *o2 = a.out2.at(p) + y * (int)a.out2.pitch + x;
-    if (a.vec_out) {
-        *reinterpret_cast<double2 *>(o1) = make_double2(w1[0][0], w1[0][1]);
-        *reinterpret_cast<double2 *>(o1 + a.out1.pitch) = make_double2(w1[1][0], w1[1][1]);
-        *reinterpret_cast<double2 *>(o2) = make_double2(w2[0][0], w2[0][1]);
-        *reinterpret_cast<double2 *>(o2 + a.out2.pitch) = make_double2(w2[1][0], w2[1][1]);
-    } else {
-        o1[0] = w1[0][0]; o1[1] = w1[0][1]; o1[a.out1.pitch] = w1[1][0]; o1[a.out1.pitch + 1] = w1[1][1];
-        o2[0] = w2[0][0]; o2[1] = w2[0][1]; o2[a.out2.pitch] = w2[1][0]; o2[a.out2.pitch + 1] = w2[1][1];
+    for (int k = 0; k < 4; ++k) {
+        if (y0 + k < H) {                                   // H is even, so rows come in pairs; keep general
+            // map build (ParallelVideoPyr.cpp:674-678), float32 arithmetic
+            const float fx = (float)upu[k], fy = (float)upv[k];
+            const float hx = fx / 2, hy = fy / 2;
+            const float xf = (float)x, yf = (float)(y0 + k);
+            const double w1 = remap_bilinear_v2(I1, ip, H, W, xf + hx, yf + hy);
+            const double w2 = remap_bilinear_v2(I2, ip, H, W, xf - hx, yf - hy);
+            o1[k * (int)a.out1.pitch] = w1;
+            o2[k * (int)a.out2.pitch] = w2;
+        }
     }
 }
 

@@ -274,9 +274,9 @@ int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int p
     lk::PyrDownArgs a{};
     a.src = src; a.dst = dst; a.H = H; a.W = W;
     a.Hd = (H + 1) / 2; a.Wd = (W + 1) / 2;
-    a.gx = (a.Wd + 127) / 128; a.gy = (a.Hd + 7) / 8;
+    a.th = 32;
+    a.gx = (a.Wd + 4 * lk::PD_WCOLS - 1) / (4 * lk::PD_WCOLS); a.gy = (a.Hd + a.th - 1) / a.th;
     a.vec_src = vec16(src.base, src.plane, src.pitch);
-    a.vec_dst = vec16(dst.base, dst.plane, dst.pitch);
     const long long n = (long long)a.gx * a.gy * planes;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
     hipLaunchKernelGGL(lk::pyrdown_kernel, dim3((unsigned)n), dim3(256), 0, s, a);
@@ -290,8 +290,7 @@ int launch_warp(lkflow_ctx *ctx, CPlanes i1, CPlanes i2, int H, int W, CPlanes c
     lk::WarpArgs a{};
     a.img1 = i1; a.img2 = i2; a.cu = cu; a.cv = cv; a.out1 = o1; a.out2 = o2;
     a.H = H; a.W = W;
-    a.gx = (W + 127) / 128; a.gy = (H + 7) / 8;
-    a.vec_out = vec16(o1.base, o1.plane, o1.pitch) && vec16(o2.base, o2.plane, o2.pitch);
+    a.gx = (W + 63) / 64; a.gy = (H + 15) / 16;
     const long long n = (long long)a.gx * a.gy * pairs;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
     hipLaunchKernelGGL(lk::warp_kernel, dim3((unsigned)n), dim3(256), 0, s, a);
