@@ -192,11 +192,11 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
             // vertical van Herk / Gil-Werman step at static chunk position K
             pre[f] = (K == 0) ? h : pre[f] + h;
             S[f] = (K < WIN - 1) ? ring[(K + 1) % WIN][f] + pre[f] : pre[f];
-            ring[K][f] = h;
+            if (K > 0) ring[K][f] = h;                          // slot 0 is never read back (see below)
         }
         if (K == WIN - 1) {
 #pragma unroll
-            for (int q = WIN - 2; q >= 0; --q)
+            for (int q = WIN - 2; q >= 1; --q)                  // suffix sums; suffix[0] (= chunk total) is never used
 #pragma unroll
                 for (int f = 0; f < 5; ++f) ring[q][f] += ring[q + 1][f];
         }

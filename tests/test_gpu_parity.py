@@ -275,3 +275,32 @@ def test_stream_leg_u8_frames_to_flow_and_centroid(gpu_ctx, oracle, torch):
         assert np.abs(host(U[p]) - uo).max() <= TOL and np.abs(host(V[p]) - vo).max() <= TOL
         c, sx, sy = oracle.flow_centroid(host(U[p]), host(V[p]), 0.5)
         assert tuple(host(rows[p])) == (float(c), sx, sy)
+
+
+def test_fuzz_random_shapes_windows_levels(gpu_ctx, lkflow, oracle):
+    """Seeded fuzz over ragged sizes (odd widths/heights, images narrower than a window, images
+    smaller than one tile, several pyramid depths): pyramid and single-level LK vs the oracle."""
+    rng = np.random.default_rng(20261004)
+    wins = [3, 5, 7, 9, 11, 13, 15, 17, 21, 25, 31]
+    worst = 0.0
+    for case in range(48):
+        win = int(rng.choice(wins))
+        if case % 3 == 0:                                     # single level, arbitrary (odd) sizes
+            h, w = int(rng.integers(1, 70)), int(rng.integers(1, 600))
+            a, b = rng.random((h, w)), rng.random((h, w))
+            u, v = gpu_ctx.getLucasKanadeOpticalFlow(a, b, win)
+            uo, vo = oracle.lucas_kanade(a, b, win)
+        else:                                                 # pyramids: sizes = odd * 2^(L-1)
+            levels = int(rng.integers(2, 6))
+            h = int(rng.integers(1, 12)) * 2 ** (levels - 1)
+            w = int(rng.integers(1, 40)) * 2 ** (levels - 1)
+            assert lkflow.getMaxLayer(w, h) >= levels
+            a, b = rng.random((h, w)), rng.random((h, w))
+            u, v = gpu_ctx.computeFlow(a, b, levels, win)
+            uo, vo = oracle.coarse_to_fine(a, b, levels, win)
+        # white-noise inputs with tiny windows are ill-conditioned: compare relative to the flow scale
+        scale = max(1.0, np.abs(uo).max(), np.abs(vo).max())
+        err = max(np.abs(u - uo).max(), np.abs(v - vo).max()) / scale
+        worst = max(worst, err)
+        assert err <= 1e-6, (case, h, w, win, err)
+    print(f"fuzz worst relative error {worst:.3e}")
