@@ -54,6 +54,23 @@ def lk0_bytes_per_pair(cols, rows, levels):
     return 8 * (4 * n[0] + 2 * n[1])
 
 
+def measured_traffic(kernel_prefix, cols, rows, pairs):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
+    (profiles/pmc_traffic.json, written by tools/prof_pmc.sh for THIS workload), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if d.get("_workload") != f"{cols}x{rows}x{pairs}":
+        return None
+    for k, v in d.items():
+        if k.startswith(kernel_prefix):
+            return int(v["hbm_read_bytes"] + v["hbm_write_bytes"])
+    return None
+
+
 def cpu_baseline(cols, rows, levels, win, budget_s=20.0):
     """Times oracle/lk_cpu_omp.c (the restated ParallelVideoPyr.cpp CPU path) on this host."""
     import synth
@@ -191,7 +208,9 @@ def main():
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK, 4),
-                "traffic": None,
+                # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, gfx950 x2
+                # FETCH_SIZE correction applied; committed under profiles/), null if not collected
+                "traffic": measured_traffic(f"lk::lk_march3_kernel<{win}, 256, true>", cols, rows, P),
                 "algorithmic_bytes_per_launch": lk0_bytes,
                 "avg_launch_ms": round(lk0_avg_s * 1e3, 4),
                 "launches_timed": lk0_n,

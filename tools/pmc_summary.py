@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc CSVs (tools/prof_pmc.sh): per kernel, mean counter value per dispatch
-over the dispatches of the LARGEST grid of that kernel (= the level-0 launches)."""
+"""Summarise rocprofv3 --pmc CSVs (tools/prof_pmc.sh): per kernel and counter, the MAXIMUM value over
+its dispatches = the level-0 launch (every counter grows with the level size; grid sizes alone do not
+identify the level because the strip-height heuristic can give levels 0 and 1 equal grids)."""
 import csv
 import glob
 import os
@@ -22,11 +23,12 @@ for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), re
             rows.append((short, g, r["Counter_Name"], float(r["Counter_Value"]), r))
             grid[short] = max(grid[short], g)
 for short, g, cname, val, r in rows:
-    if g == grid[short]:
-        acc[short][cname].append(val)
+    acc[short][cname].append(val)
+import json
+traffic = {}
 for k in sorted(acc):
     print(f"== {k}  (grid {grid[k]} work-items)")
-    c = {n: sum(v) / len(v) for n, v in acc[k].items()}
+    c = {n: max(v) for n, v in acc[k].items()}
     for n in sorted(c):
         print(f"   {n:32s} {c[n]:18.1f}")
     if "FETCH_SIZE" in c:
@@ -34,8 +36,17 @@ for k in sorted(acc):
         print(f"   -> HBM read  ~ {c['FETCH_SIZE'] * 1024 * 2 / 1e6:10.1f} MB/launch (FETCH_SIZE KiB x2 correction)")
     if "WRITE_SIZE" in c:
         print(f"   -> HBM write ~ {c['WRITE_SIZE'] * 1024 / 1e6:10.1f} MB/launch")
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        traffic[k] = {"grid_work_items": grid[k], "hbm_read_bytes": c["FETCH_SIZE"] * 1024 * 2,
+                      "hbm_write_bytes": c["WRITE_SIZE"] * 1024,
+                      "note": "rocprofv3 --pmc FETCH_SIZE (KiB, x2 gfx950 read correction) / WRITE_SIZE (KiB), "
+                              "of the level-0 launch (max over dispatches)"}
     if "SQ_WAVES" in c and c["SQ_WAVES"]:
         w = c["SQ_WAVES"]
         for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"):
             if n in c:
                 print(f"   -> {n}/wave = {c[n] / w:10.1f}")
+
+if len(sys.argv) > 2:
+    with open(sys.argv[2], "w") as fh:
+        json.dump(traffic, fh, indent=1)
