@@ -141,23 +141,30 @@ __device__ __forceinline__ int cv_round_f(float t)
 }
 
 // cv::remap INTER_LINEAR / BORDER_CONSTANT(0) sample of src at float map coordinate (mx,my)
-// (OpenCV 2.4 imgwarp.cpp: 1/32-pixel fixed point, float weight table, fp64 blend).
-__device__ __forceinline__ double remap_bilinear(const double *src, long long pitch, int H, int W,
-                                                 float mx, float my)
+// (OpenCV 2.4 imgwarp.cpp: 1/32-pixel fixed point, float weight table, fp64 blend, taps outside the
+// image contribute 0).  When all four taps are inside, the two horizontal taps of a row are fetched
+// as one 16-byte load.
+__device__ __forceinline__ double remap_bilinear(const double *src, int pitch, int H, int W, float mx,
+                                                    float my)
 {
     const int sx = cv_round_f(mx * 32.0f);
     const int sy = cv_round_f(my * 32.0f);
     const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
     const float a = (float)(sx & 31) * (1.0f / 32), b = (float)(sy & 31) * (1.0f / 32);
     const float w0 = (1.0f - b) * (1.0f - a), w1 = (1.0f - b) * a, w2 = b * (1.0f - a), w3 = b * a;
-    const double *r0 = src + (long long)iy * pitch + ix;
-    const double *r1 = r0 + pitch;
     double v0, v1, v2, v3;
     if ((unsigned)ix < (unsigned)(W - 1) && (unsigned)iy < (unsigned)(H - 1)) {   // all four taps inside
-        v0 = r0[0]; v1 = r0[1]; v2 = r1[0]; v3 = r1[1];
+        const double *r0 = src + iy * pitch + ix;
+        // 8-byte aligned 16-byte loads: dword-aligned multi-dword global loads are legal on gfx9
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        const d2u t0 = *reinterpret_cast<const d2u *>(r0);
+        const d2u t1 = *reinterpret_cast<const d2u *>(r0 + pitch);
+        v0 = t0.x; v1 = t0.y; v2 = t1.x; v3 = t1.y;
     } else {
         const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W;
         const bool y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
+        const double *r0 = src + (long long)iy * pitch + ix;
+        const double *r1 = r0 + pitch;
         v0 = (y0 && x0) ? r0[0] : 0.0;
         v1 = (y0 && x1) ? r0[1] : 0.0;
         v2 = (y1 && x0) ? r1[0] : 0.0;
@@ -166,16 +173,5 @@ __device__ __forceinline__ double remap_bilinear(const double *src, long long pi
     return v0 * (double)w0 + v1 * (double)w1 + v2 * (double)w2 + v3 * (double)w3;
 }
 
-// Map build (ParallelVideoPyr.cpp:674-678) + remap of both images at fine pixel (y,x):
-// image 1 sampled at (x + f.x/2, y + f.y/2), image 2 at (x - f.x/2, y - f.y/2); float32 map math.
-__device__ __forceinline__ void warp_pair_at(const double *I1, const double *I2, long long pitch,
-                                             int H, int W, int y, int x, double upu, double upv,
-                                             double &w1, double &w2)
-{
-    const float fx = (float)upu, fy = (float)upv;
-    const float hx = fx / 2, hy = fy / 2;
-    w1 = remap_bilinear(I1, pitch, H, W, (float)x + hx, (float)y + hy);
-    w2 = remap_bilinear(I2, pitch, H, W, (float)x - hx, (float)y - hy);
-}
 
 }  // namespace lk

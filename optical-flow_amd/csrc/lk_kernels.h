@@ -1,9 +1,9 @@
 // lk_kernels.h -- HIP kernels of the dense pyramidal LK path (gfx950 / CDNA4, wave64, fp64).
 //
 // Kernel inventory (one per stage of SURVEY.md 8(a)); every kernel is batched over blockIdx.z:
-//   pyrdown_kernel        a2   cv::pyrDown of n planes
+//   pyrdown_kernel        a2   cv::pyrDown of n planes (row-marching, DPP neighbour taps)
 //   pyrup_kernel          a9   cv::pyrUp (stage entry point / tests; the pipeline fuses it)
-//   warp_kernel           a9+a10+a11  pyrUp(flow) -> float map -> fixed-point bilinear remap
+//   warp_kernel           a9+a10+a11  pyrUp(flow) -> float map -> fixed-point bilinear remap (1x4 strips)
 //   lk_march3_kernel<WIN> a3..a8  derivatives, products, win x win sums, 2x2 solve, += pyrUp(flow)  (lk_march3.h)
 //   lk_naive_kernel       a3..a8  per-pixel restatement (cross-check only)
 //   u8_to_f64_kernel      a15  convertTo(CV_64F, 1/255)
@@ -183,48 +183,6 @@ __device__ __forceinline__ void pyrup_strip4(const double *c, int cp, int Hc, in
     o[3] = ((h[2] + h[3]) * 4) * (1.0 / 64);                // y0 + 3
 }
 
-// remap_bilinear() with the two horizontal taps of each row fetched as one 16-byte load
-__device__ __forceinline__ double remap_bilinear_v2(const double *src, int pitch, int H, int W, float mx,
-                                                    float my)
-{
-    const int sx = cv_round_f(mx * 32.0f);
-    const int sy = cv_round_f(my * 32.0f);
-    const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
-    const float a = (float)(sx & 31) * (1.0f / 32), b = (float)(sy & 31) * (1.0f / 32);
-    const float w0 = (1.0f - b) * (1.0f - a), w1 = (1.0f - b) * a, w2 = b * (1.0f - a), w3 = b * a;
-    double v0, v1, v2, v3;
-#if defined(LKW_TIMING_NOSLOW)   /* timing experiment only: wrong at the image border */
-    {
-        const int cx = min(max(ix, 0), W - 2), cy = min(max(iy, 0), H - 2);
-        const double *r0 = src + cy * pitch + cx;
-        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-        const d2u t0 = *reinterpret_cast<const d2u *>(r0);
-        const d2u t1 = *reinterpret_cast<const d2u *>(r0 + pitch);
-        v0 = t0.x; v1 = t0.y; v2 = t1.x; v3 = t1.y;
-    }
-    if (false) {
-#else
-    if ((unsigned)ix < (unsigned)(W - 1) && (unsigned)iy < (unsigned)(H - 1)) {   // all four taps inside
-#endif
-        const double *r0 = src + iy * pitch + ix;
-        // 8-byte aligned 16-byte loads: dword-aligned multi-dword global loads are legal on gfx9
-        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-        const d2u t0 = *reinterpret_cast<const d2u *>(r0);
-        const d2u t1 = *reinterpret_cast<const d2u *>(r0 + pitch);
-        v0 = t0.x; v1 = t0.y; v2 = t1.x; v3 = t1.y;
-    } else {
-        const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W;
-        const bool y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
-        const double *r0 = src + (long long)iy * pitch + ix;
-        const double *r1 = r0 + pitch;
-        v0 = (y0 && x0) ? r0[0] : 0.0;
-        v1 = (y0 && x1) ? r0[1] : 0.0;
-        v2 = (y1 && x0) ? r1[0] : 0.0;
-        v3 = (y1 && x1) ? r1[1] : 0.0;
-    }
-    return v0 * (double)w0 + v1 * (double)w1 + v2 * (double)w2 + v3 * (double)w3;
-}
-
 __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
 {
     const unsigned n = gridDim.x;
@@ -238,12 +196,8 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     const int H = a.H, W = a.W;
     if (x >= W || y0 >= H) return;
     double upu[4], upv[4];
-#if defined(LKW_TIMING_NOUP)     /* timing experiment only */
-    for (int k = 0; k < 4; ++k) { upu[k] = 1.5 + 1e-3 * x; upv[k] = -0.75 + 1e-3 * y0; }
-#else
     pyrup_strip4(a.cu.at(p), (int)a.cu.pitch, H >> 1, W >> 1, y0, x, upu);
     pyrup_strip4(a.cv.at(p), (int)a.cv.pitch, H >> 1, W >> 1, y0, x, upv);
-#endif
     const double *I1 = a.img1.at(p), *I2 = a.img2.at(p);
     const int ip = (int)a.img1.pitch;
     double *o1 = a.out1.at(p) + y0 * (int)a.out1.pitch + x;
@@ -255,8 +209,8 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
             const float fx = (float)upu[k], fy = (float)upv[k];
             const float hx = fx / 2, hy = fy / 2;
             const float xf = (float)x, yf = (float)(y0 + k);
-            const double w1 = remap_bilinear_v2(I1, ip, H, W, xf + hx, yf + hy);
-            const double w2 = remap_bilinear_v2(I2, ip, H, W, xf - hx, yf - hy);
+            const double w1 = remap_bilinear(I1, ip, H, W, xf + hx, yf + hy);
+            const double w2 = remap_bilinear(I2, ip, H, W, xf - hx, yf - hy);
             o1[k * (int)a.out1.pitch] = w1;
             o2[k * (int)a.out2.pitch] = w2;
         }
