@@ -140,48 +140,20 @@ __global__ __launch_bounds__(256) void pyrup_kernel(CPlanes src, int Hc, int Wc,
 // Warp of one pyramid level: up-sample the coarse flow, build the float map, remap both images.
 // ParallelVideoPyr.cpp:646-703.  H, W are the fine level's size (= 2*Hc, 2*Wc, both even).
 //
-// What bounds this kernel is the vector-memory front end (L1 line look-ups per gather instruction),
-// so lanes map to CONSECUTIVE columns -- a gather instruction then touches 4-5 full 128-byte lines
-// instead of 8 half-used ones -- and the two horizontal taps of a row are fetched as one 16-byte
-// load.  One thread = a 1 x 4 column strip (x, y..y+3), y a multiple of 4: the strip spans two coarse
-// rows, so cv::pyrUp needs 4 coarse rows x 3 columns per flow plane (branch-free borders, same
-// roundings as pyrup_at()).  Block = 4 waves = 64 columns x 16 rows; XCD-aware 1-D grid.
+// Row-marching: thread = one column x, lanes = consecutive columns (a gather instruction touches 4-5
+// full 128-byte lines; the two horizontal taps of a row are one 16-byte load), a wave marches down a
+// strip of `th` rows two at a time.  cv::pyrUp is evaluated incrementally: the three horizontally
+// filtered coarse rows s(i-1), s(i), s(i+1) of the current row pair live in registers and ONE new
+// coarse row (3 loads per flow plane) is fetched per pair (branch-free asymmetric borders, same
+// roundings as pyrup_at()).  Block = 4 waves = 256 columns; XCD-aware 1-D grid.
 // ------------------------------------------------------------------------------------------------
 struct WarpArgs {
     CPlanes img1, img2, cu, cv;
     Planes out1, out2;
     int H, W;
     int gx, gy;
+    int th;           // rows per block (even)
 };
-
-// the four fine rows y0..y0+3 (y0 = 4m) of cv::pyrUp at fine column x
-__device__ __forceinline__ void pyrup_strip4(const double *c, int cp, int Hc, int Wc, int y0, int x,
-                                             double (&o)[4])
-{
-    const int j = x >> 1;
-    const int jm = j > 0 ? j - 1 : 0, jp = j < Wc - 1 ? j + 1 : Wc - 1;
-    const bool single = Wc == 1, left = j == 0, right = j == Wc - 1, odd = (x & 1) != 0;
-    const double mB = single ? 8.0 : (right ? 7.0 : 6.0);
-    const double wA = (single || left) ? 0.0 : 1.0;
-    const double wC = (single || right) ? 0.0 : (left ? 2.0 : 1.0);
-    const bool dup = single || right;
-    const int i = y0 >> 1;                                  // coarse rows i-1 .. i+2 (clamped like r101(2k,2Hc)/2)
-    double h[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int kk = i - 1 + k;
-        const int sr = kk < 0 ? min(1, Hc - 1) : (kk > Hc - 1 ? Hc - 1 : kk);
-        const double *r = c + sr * cp;
-        const double A = r[jm], B = r[j], C = r[jp];
-        const double ev = (A * wA + B * mB) + C * wC;
-        const double od = (B + (dup ? B : C)) * 4;
-        h[k] = odd ? od : ev;
-    }
-    o[0] = (h[0] + h[1] * 6 + h[2]) * (1.0 / 64);           // y0     = 2i
-    o[1] = ((h[1] + h[2]) * 4) * (1.0 / 64);                // y0 + 1
-    o[2] = (h[1] + h[2] * 6 + h[3]) * (1.0 / 64);           // y0 + 2 = 2(i+1)
-    o[3] = ((h[2] + h[3]) * 4) * (1.0 / 64);                // y0 + 3
-}
 
 __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
 {
@@ -190,30 +162,53 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     const int bx = tile % a.gx; tile /= a.gx;
     const int by = tile % a.gy;
     const int p = tile / a.gy;
-    const int wrow = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x = bx * 64 + (threadIdx.x & 63);
-    const int y0 = (by * 4 + wrow) * 4;
-    const int H = a.H, W = a.W;
-    if (x >= W || y0 >= H) return;
-    double upu[4], upv[4];
-    pyrup_strip4(a.cu.at(p), (int)a.cu.pitch, H >> 1, W >> 1, y0, x, upu);
-    pyrup_strip4(a.cv.at(p), (int)a.cv.pitch, H >> 1, W >> 1, y0, x, upv);
+    const int x = bx * 256 + threadIdx.x;
+    const int H = a.H, W = a.W, Hc = H >> 1, Wc = W >> 1;
+    const int y0 = by * a.th, y1 = min(y0 + a.th, H);
+    if (x >= W) return;
+
+    // per-thread pyrUp column selectors (see pyrup_h())
+    const int j = x >> 1;
+    const int jm = j > 0 ? j - 1 : 0, jp = j < Wc - 1 ? j + 1 : Wc - 1;
+    const bool single = Wc == 1, left = j == 0, right = j == Wc - 1, odd = (x & 1) != 0;
+    const double mB = single ? 8.0 : (right ? 7.0 : 6.0);
+    const double wA = (single || left) ? 0.0 : 1.0;
+    const double wC = (single || right) ? 0.0 : (left ? 2.0 : 1.0);
+    const bool dup = single || right;
+    const double *CU = a.cu.at(p), *CV = a.cv.at(p);
+    const int cpu = (int)a.cu.pitch, cpv = (int)a.cv.pitch;
+    auto srow = [&](int k) { return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };   // r101(2k,2Hc)/2
+    auto htap = [&](const double *r) __attribute__((always_inline)) -> double {
+        const double A = r[jm], B = r[j], C = r[jp];
+        const double ev = (A * wA + B * mB) + C * wC;
+        const double od = (B + (dup ? B : C)) * 4;
+        return odd ? od : ev;
+    };
+
     const double *I1 = a.img1.at(p), *I2 = a.img2.at(p);
-    const int ip = (int)a.img1.pitch;
-    double *o1 = a.out1.at(p) + y0 * (int)a.out1.pitch + x;
-    double *o2 = a.out2.at(p) + y0 * (int)a.out2.pitch + x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (y0 + k < H) {                                   // H is even, so rows come in pairs; keep general
-            // map build (ParallelVideoPyr.cpp:674-678), float32 arithmetic
-            const float fx = (float)upu[k], fy = (float)upv[k];
-            const float hx = fx / 2, hy = fy / 2;
-            const float xf = (float)x, yf = (float)(y0 + k);
-            const double w1 = remap_bilinear(I1, ip, H, W, xf + hx, yf + hy);
-            const double w2 = remap_bilinear(I2, ip, H, W, xf - hx, yf - hy);
-            o1[k * (int)a.out1.pitch] = w1;
-            o2[k * (int)a.out2.pitch] = w2;
-        }
+    const int ip = (int)a.img1.pitch, op1 = (int)a.out1.pitch, op2 = (int)a.out2.pitch;
+    double *o1 = a.out1.at(p) + y0 * op1 + x;
+    double *o2 = a.out2.at(p) + y0 * op2 + x;
+    const float xf = (float)x;
+
+    int i = y0 >> 1;                                        // y0 is even
+    double hu0 = htap(CU + srow(i - 1) * cpu), hu1 = htap(CU + srow(i) * cpu);
+    double hv0 = htap(CV + srow(i - 1) * cpv), hv1 = htap(CV + srow(i) * cpv);
+    for (int y = y0; y < y1; y += 2, ++i) {
+        const double hu2 = htap(CU + srow(i + 1) * cpu), hv2 = htap(CV + srow(i + 1) * cpv);
+        const double upu0 = (hu0 + hu1 * 6 + hu2) * (1.0 / 64), upu1 = ((hu1 + hu2) * 4) * (1.0 / 64);
+        const double upv0 = (hv0 + hv1 * 6 + hv2) * (1.0 / 64), upv1 = ((hv1 + hv2) * 4) * (1.0 / 64);
+        // map build (ParallelVideoPyr.cpp:674-678), float32 arithmetic
+        const float hx0 = (float)upu0 / 2, hy0 = (float)upv0 / 2, hx1 = (float)upu1 / 2, hy1 = (float)upv1 / 2;
+        const float yf0 = (float)y, yf1 = (float)(y + 1);
+        const double a0 = remap_bilinear(I1, ip, H, W, xf + hx0, yf0 + hy0);
+        const double b0 = remap_bilinear(I2, ip, H, W, xf - hx0, yf0 - hy0);
+        const double a1 = remap_bilinear(I1, ip, H, W, xf + hx1, yf1 + hy1);
+        const double b1 = remap_bilinear(I2, ip, H, W, xf - hx1, yf1 - hy1);
+        o1[0] = a0; o2[0] = b0;
+        o1[op1] = a1; o2[op2] = b1;                         // H is even: row y+1 exists
+        o1 += 2 * op1; o2 += 2 * op2;
+        hu0 = hu1; hu1 = hu2; hv0 = hv1; hv1 = hv2;
     }
 }
 

@@ -290,7 +290,8 @@ int launch_warp(lkflow_ctx *ctx, CPlanes i1, CPlanes i2, int H, int W, CPlanes c
     lk::WarpArgs a{};
     a.img1 = i1; a.img2 = i2; a.cu = cu; a.cv = cv; a.out1 = o1; a.out2 = o2;
     a.H = H; a.W = W;
-    a.gx = (W + 63) / 64; a.gy = (H + 15) / 16;
+    a.th = 16;                                   // even; two rows per iteration
+    a.gx = (W + 255) / 256; a.gy = (H + a.th - 1) / a.th;
     const long long n = (long long)a.gx * a.gy * pairs;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
     hipLaunchKernelGGL(lk::warp_kernel, dim3((unsigned)n), dim3(256), 0, s, a);
