@@ -274,7 +274,10 @@ int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int p
     lk::PyrDownArgs a{};
     a.src = src; a.dst = dst; a.H = H; a.W = W;
     a.Hd = (H + 1) / 2; a.Wd = (W + 1) / 2;
-    a.th = 32;
+#ifndef LK_PD_TH
+#define LK_PD_TH 16
+#endif
+    a.th = LK_PD_TH;
     a.gx = (a.Wd + 4 * lk::PD_WCOLS - 1) / (4 * lk::PD_WCOLS); a.gy = (a.Hd + a.th - 1) / a.th;
     a.vec_src = vec16(src.base, src.plane, src.pitch);
     const long long n = (long long)a.gx * a.gy * planes;
@@ -290,7 +293,10 @@ int launch_warp(lkflow_ctx *ctx, CPlanes i1, CPlanes i2, int H, int W, CPlanes c
     lk::WarpArgs a{};
     a.img1 = i1; a.img2 = i2; a.cu = cu; a.cv = cv; a.out1 = o1; a.out2 = o2;
     a.H = H; a.W = W;
-    a.th = 16;                                   // even; two rows per iteration
+#ifndef LK_WARP_TH
+#define LK_WARP_TH 16
+#endif
+    a.th = LK_WARP_TH;                           // even; two rows per iteration
     a.gx = (W + 255) / 256; a.gy = (H + a.th - 1) / a.th;
     const long long n = (long long)a.gx * a.gy * pairs;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
