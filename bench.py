@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--config", default="1080p", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time of every stage")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step into a HIP graph and replay it (launch-bound small batches); "
+                         "the per-kernel HIP-event roofline is then taken from a separate eager pass")
     args = ap.parse_args()
 
     import torch
@@ -140,8 +143,22 @@ def main():
     ctx.reserve(rows, cols, levels, P)
     stream = torch.cuda.current_stream()
 
-    def step():
+    def eager_step():
         ctx.compute_batch(prev, nxt, levels, win, out=(U, V), stream=stream)
+
+    step = eager_step
+    graph = None
+    if args.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ctx.compute_batch(prev, nxt, levels, win, out=(U, V), stream=side)      # warm (workspace, occupancy cache)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                ctx.compute_batch(prev, nxt, levels, win, out=(U, V), stream=side)
+        torch.cuda.current_stream().wait_stream(side)
+        step = graph.replay
 
     def barrier():
         torch.cuda.synchronize()
@@ -153,7 +170,14 @@ def main():
         step()
     barrier()
     # dominant kernel (LK at level 0) bracketed by HIP events on its own stream, live in the timed region
-    if args.profile_all:
+    if args.graph:                       # events cannot be recorded by the library inside a replayed graph:
+        ctx.profile(lkf.LKFLOW_STAGE_LK, 0)        # take the dominant kernel's time from eager launches
+        for _ in range(5):
+            eager_step()
+        barrier()
+        prof_eager = ctx.profile_read()
+        ctx.profile(False)
+    elif args.profile_all:
         ctx.profile()
     else:
         ctx.profile(lkf.LKFLOW_STAGE_LK, 0)
@@ -163,7 +187,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    prof = ctx.profile_read()
+    prof = prof_eager if args.graph else ctx.profile_read()
     ctx.profile(False)
 
     if dist is not None:
@@ -199,6 +223,7 @@ def main():
                 "cols": cols, "rows": rows, "pyr_levels": levels, "win": win,
                 "pairs_per_step_per_gpu": P,
                 "parallelism": f"frame-pair sharding x{world} (no data-path collective)",
+                "launch": "hip-graph replay" if args.graph else "eager",
             },
             "frame_pairs_per_s": round(P * world * args.steps / dt, 2),
             "roofline": {
