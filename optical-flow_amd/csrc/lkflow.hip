@@ -197,7 +197,7 @@ inline int pick_tile_rows(int H, int R, long long blocks_per_strip, long long sl
     int th = H;
     for (int gy = 1; gy <= H; ++gy) {
         const int t = (H + gy - 1) / gy;
-        if (t < 24 && gy > 1) break;
+        if (t < 6 && gy > 1) break;       // tiny strips only ever win when the grid is far below one round
         if ((H + t - 1) / t != gy) continue;
         const long long nblk = blocks_per_strip * gy;
         const long long cost = ((nblk + slots - 1) / slots) * (t + 2 * R + 6);
