@@ -220,6 +220,7 @@ struct LKArgs {
     CPlanes cu, cv;   // coarse total flow (H/2 x W/2), only if HAS_UP
     int H, W;
     int th;           // output rows per block
+    unsigned long long *dbg;   // diagnostic builds only (LK3_STAMPS): per-wave segment cycle totals
 };
 
 // ------------------------------------------------------------------------------------------------

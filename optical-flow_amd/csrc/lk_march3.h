@@ -136,8 +136,15 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
 
     // One marched row at chunk position K (compile-time): the chunk loop below is unrolled WIN
     // times so that every ring access is a plain register (no dispatch, no copies).
+#ifdef LK3_STAMPS
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+#define LK3_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#else
+#define LK3_STAMP(var)
+#endif
     auto row = [&](auto kc, int i) __attribute__((always_inline)) {
         constexpr int K = decltype(kc)::value;
+        LK3_STAMP(t0);
         const int bsel = i & 1;
         const int yy = yy0 + i;
         const bool row_in = yy >= 0 && yy < H;
@@ -174,13 +181,16 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
             fy = keep ? fy : 0.0;
             p[0] = fx * fx; p[1] = fy * fy; p[2] = fx * fy; p[3] = fx * ft; p[4] = fy * ft;
         }
+        LK3_STAMP(t1);
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
             const double q = p[f] + dpp_swap1(p[f]);
             s_p[bsel][f][PP + t] = p[f];
             s_q[bsel][f][PQ + (t >> 1)] = q;                    // both lanes of a pair store the same value
         }
+        LK3_STAMP(t2);
         __syncthreads();
+        LK3_STAMP(t3);
 
         double S[5];
 #pragma unroll
@@ -201,9 +211,14 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
                 for (int f = 0; f < 5; ++f) ring[q][f] += ring[q + 1][f];
         }
 
+        LK3_STAMP(t4);
         // rotate: the only wait for the prefetch
         pa0 = ca0; pa1 = ca1; pb0 = cb0; pb1 = cb1;
         ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
+#ifdef LK3_STAMPS
+        asm volatile("" :: "v"(pa0), "v"(ca0), "v"(ca1), "v"(cb0), "v"(cb1));
+#endif
+        LK3_STAMP(t5);
 
         if (out_row && is_out) {
             double u = 0.0, v = 0.0;
@@ -242,6 +257,10 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
             a.u.at(pair)[y * (int)a.u.pitch + x] = u;
             a.v.at(pair)[y * (int)a.v.pitch + x] = v;
         }
+#ifdef LK3_STAMPS
+        LK3_STAMP(t6);
+        seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2; seg[3] += t4 - t3; seg[4] += t5 - t4; seg[5] += t6 - t5;
+#endif
     };
 
     for (int base = 0; base < nmarch; base += WIN) {
@@ -249,6 +268,14 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
             ((base + Ks < nmarch ? (row(std::integral_constant<int, Ks>{}, base + Ks), 0) : 0), ...);
         }(std::make_integer_sequence<int, WIN>{});
     }
+#ifdef LK3_STAMPS
+    // diagnostic build only: per-segment cycle totals of wave 0 of every block -> debug buffer (a.dbg)
+    if (a.dbg && (threadIdx.x & 63) == 0) {
+        const unsigned wid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (TX / 64) + (threadIdx.x >> 6);
+        for (int k = 0; k < 6; ++k) a.dbg[wid * 8 + k] = seg[k];
+        a.dbg[wid * 8 + 6] = nmarch;
+    }
+#endif
 }
 
 }  // namespace lk

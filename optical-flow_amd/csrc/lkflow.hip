@@ -220,6 +220,23 @@ void launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipSt
     if (th > a.H) th = a.H;
     a.th = th;
     dim3 grid(gx, (a.H + th - 1) / th, pairs);
+#ifdef LK3_STAMPS
+    {   // diagnostic build: dump the stamps of the largest launch to $LKFLOW_STAMPS_OUT after the run
+        static unsigned long long *dbuf = nullptr; static size_t dn = 0;
+        const size_t nw = (size_t)grid.x * grid.y * grid.z * (TX / 64);
+        if (has_up && nw * 8 > dn) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc((void **)&dbuf, nw * 64); dn = nw * 8; }
+        a.dbg = (has_up && nw * 8 == dn) ? dbuf : nullptr;
+        if (a.dbg && getenv("LKFLOW_STAMPS_OUT")) {
+            hipLaunchKernelGGL((lk::lk_march3_kernel<WIN, TX, true>), grid, dim3(TX), 0, s, a);
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h(dn);
+            (void)hipMemcpy(h.data(), dbuf, dn * 8, hipMemcpyDeviceToHost);
+            FILE *f = fopen(getenv("LKFLOW_STAMPS_OUT"), "wb");
+            if (f) { fwrite(h.data(), 8, dn, f); fclose(f); }
+            return;
+        }
+    }
+#endif
     if (has_up)
         hipLaunchKernelGGL((lk::lk_march3_kernel<WIN, TX, true>), grid, dim3(TX), 0, s, a);
     else
