@@ -38,6 +38,16 @@ def main():
         crop.tofile(os.path.join(OUT, f"{name}_640x448.u8"))
         print(name, g.shape, "->", crop.shape, "mean", crop.mean())
 
+    # BASELINE config 0b input: hand1/hand2 (3264x2448, unused by every reference source, no golden).
+    # A centred 816x612 crop (= the 3264x2448 frame / 4 in each dimension, so 3 levels are legal:
+    # 816 = 2^4*51, 612 = 2^2*153) keeps the fixture small; EXIF orientation ignored like OpenCV 2.4.
+    for name in ("hand1", "hand2"):
+        g = decode_gray(os.path.join(REF, "testdata", name + ".jpg"))
+        assert g.shape == (2448, 3264), g.shape
+        crop = np.ascontiguousarray(g[918:918 + 612, 1224:1224 + 816])
+        crop.tofile(os.path.join(OUT, f"{name}_816x612.u8"))
+        print(name, g.shape, "->", crop.shape, "mean", crop.mean())
+
     arrays = {}
     for name in ("U2Test", "V2Test", "UPyrTest", "VPyrTest", "V2"):
         a = np.loadtxt(os.path.join(REF, name + ".txt"), dtype=np.float64)

@@ -304,3 +304,33 @@ def test_fuzz_random_shapes_windows_levels(gpu_ctx, lkflow, oracle):
         worst = max(worst, err)
         assert err <= 1e-6, (case, h, w, win, err)
     print(f"fuzz worst relative error {worst:.3e}")
+
+
+def test_config0b_hand_images_vs_oracle(gpu_ctx, oracle):
+    """BASELINE config 0b: real camera frames (hand1/hand2.jpg, centred 816x612 crop), 3 levels,
+    15x15 window.  The reference never reads these files and holds no golden for them, so the check
+    is HIP path vs the (golden-pinned) oracle at the reference's own bar."""
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    a = oracle.u8_to_f64(np.fromfile(os.path.join(g, "hand1_816x612.u8"), dtype=np.uint8).reshape(612, 816))
+    b = oracle.u8_to_f64(np.fromfile(os.path.join(g, "hand2_816x612.u8"), dtype=np.uint8).reshape(612, 816))
+    u, v = gpu_ctx.computeFlow(a, b, 3, 15)
+    uo, vo = oracle.coarse_to_fine(a, b, 3, 15)
+    scale = max(1.0, np.abs(uo).max(), np.abs(vo).max())
+    assert np.abs(u - uo).max() <= TOL * scale and np.abs(v - vo).max() <= TOL * scale
+    print(f"hand crop: max|du|={np.abs(u - uo).max():.3e} (flow range {np.abs(uo).max():.1f} px)")
+
+
+def test_full_size_8k_w31_march_equals_per_pixel(gpu_ctx, lkflow, torch):
+    """BASELINE config 4 shape at FULL size (7680x4320, 5 levels, 31x31), one pair: tiled kernels ==
+    per-pixel kernels (reference summation order)."""
+    import synth
+    prev, nxt = synth.frame_pairs_torch(1, 4320, 7680, "cuda", seed=9)
+    u, v = gpu_ctx.compute_batch(prev, nxt, 5, 31)
+    gpu_ctx.set_option(lkflow.LKFLOW_OPT_IMPL, 1)
+    try:
+        un, vn = gpu_ctx.compute_batch(prev, nxt, 5, 31)
+    finally:
+        gpu_ctx.set_option(lkflow.LKFLOW_OPT_IMPL, 0)
+    torch.cuda.synchronize()
+    assert (u - un).abs().max().item() <= TOL and (v - vn).abs().max().item() <= TOL
