@@ -148,6 +148,16 @@ int lkflow_u8_to_f64_dev(lkflow_ctx *ctx, const unsigned char *src, double *dst,
                          void *stream);
 
 /*
+ * The video loop's last pre-processing step, i.e. what PRODUCES the hot call's CV_64F inputs from the
+ * 8-bit frame difference (ParallelVideoPyr.cpp:803-813): threshold(diff, thresh, 255, THRESH_TOZERO);
+ * Sobel x + Sobel y (CV_64F, 3x3, reflect-101); dilate x2; erode x2 (3x3 rectangle, outside ignored).
+ * src: n_planes uint8 planes (rows x cols, row step src_step_bytes); dst: n_planes fp64 planes.
+ */
+int lkflow_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *src, size_t src_plane_stride_bytes,
+                           int n_planes, int rows, int cols, size_t src_step_bytes, int thresh, double *dst,
+                           size_t dst_plane_stride_bytes, size_t dst_step_bytes, void *stream);
+
+/*
  * Flow consumer of the video loop (ParallelVideoPyr.cpp:845-873), batched and fused:
  * for each pair, out[3*p+0] = number of pixels with sqrt(u*u+v*v) >= thresh,
  * out[3*p+1] = sum of their column indices, out[3*p+2] = sum of their row indices (fp64, exact

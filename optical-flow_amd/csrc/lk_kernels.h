@@ -6,6 +6,7 @@
 //   warp_kernel           a9+a10+a11  pyrUp(flow) -> float map -> fixed-point bilinear remap (1x4 strips)
 //   lk_march3_kernel<WIN> a3..a8  derivatives, products, win x win sums, 2x2 solve, += pyrUp(flow)  (lk_march3.h)
 //   lk_naive_kernel       a3..a8  per-pixel restatement (cross-check only)
+//   edge_map_kernel       f2   threshold + Sobel x+y + dilate x2 + erode x2 (uint8 diff -> CV_64F input)
 //   u8_to_f64_kernel      a15  convertTo(CV_64F, 1/255)
 //   centroid_kernel       f1   |flow| threshold + centroid sums
 #pragma once
@@ -259,6 +260,109 @@ __global__ __launch_bounds__(256) void lk_naive_kernel(LKArgs a, int win)
     }
     a.u.at(pair)[(long long)y * a.u.pitch + x] = u;
     a.v.at(pair)[(long long)y * a.v.pitch + x] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge map: the step of the video loop that PRODUCES the hot call's CV_64F inputs from the 8-bit frame
+// difference (ParallelVideoPyr.cpp:803-813): threshold TOZERO -> Sobel x + Sobel y (3x3, reflect-101)
+// -> dilate x2 -> erode x2 (3x3 rectangle; two iterations == one 5x5, as OpenCV 2.4 itself rewrites
+// them; pixels outside the image never win).  Every intermediate is a small exact integer, so the
+// tile pipeline works in int32 LDS planes and converts once at the end:
+//   thresholded pixels (T+10)^2 -> E = sx+sy (T+8)^2 -> row max -> column max = D (T+4)^2
+//   -> row min -> column min = out T^2.          Block = 256 threads = a 64 x 16 output tile.
+// ------------------------------------------------------------------------------------------------
+struct EdgeArgs {
+    const unsigned char *src;   // n_planes x rows x cols, contiguous planes, row pitch = src_pitch bytes
+    long long src_plane, src_pitch;
+    Planes dst;
+    int H, W, thresh;
+    int gx, gy;
+};
+
+constexpr int EM_TW = 64, EM_TH = 16;
+
+__global__ __launch_bounds__(256) void edge_map_kernel(EdgeArgs a)
+{
+    constexpr int PW = EM_TW + 10, PH = EM_TH + 10;     // thresholded pixels
+    constexpr int EW = EM_TW + 8, EH = EM_TH + 8;       // Sobel sum
+    constexpr int DW = EM_TW + 4, DH = EM_TH + 4;       // dilated
+    __shared__ int s_t[PH][PW];
+    __shared__ int s_e[EH][EW];
+    __shared__ int s_h[EH][DW];                         // row max of E; later row min of D ([DH][EM_TW])
+    __shared__ int s_d[DH][DW];
+
+    const unsigned n = gridDim.x;
+    unsigned tile = xcd_tile_id(blockIdx.x, n);
+    const int bx = tile % a.gx; tile /= a.gx;
+    const int by = tile % a.gy;
+    const int plane = tile / a.gy;
+    const int H = a.H, W = a.W, t = threadIdx.x;
+    const int x0 = bx * EM_TW, y0 = by * EM_TH;
+    const unsigned char *src = a.src + (long long)plane * a.src_plane;
+
+    // thresholded pixels, reflect-101 (only the Sobel taps of in-image E positions ever read them)
+    for (int i = t; i < PH * PW; i += 256) {
+        const int r = i / PW, c = i - r * PW;
+        const int yy = r101(y0 - 5 + r, H), xx = r101(x0 - 5 + c, W);
+        const int v = src[(long long)yy * a.src_pitch + xx];
+        s_t[r][c] = v > a.thresh ? v : 0;
+    }
+    __syncthreads();
+    // E = Sobel x + Sobel y at (y0-4+r, x0-4+c); positions outside the image = "never wins" for the max
+    for (int i = t; i < EH * EW; i += 256) {
+        const int r = i / EW, c = i - r * EW;
+        const int yy = y0 - 4 + r, xx = x0 - 4 + c;
+        int e = INT_MIN;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            // s_t index of (yy,xx) is [r+1][c+1]; neighbours of border pixels must be the REFLECTED image
+            // pixels, which is what s_t holds only if the neighbour coordinate itself was reflected:
+            // s_t[r+1+dy][c+1+dx] holds pixel r101(yy+dy), r101(xx+dx)  (same mapping) -> correct
+            const int tl = s_t[r][c], tc = s_t[r][c + 1], tr = s_t[r][c + 2];
+            const int ml = s_t[r + 1][c], mr = s_t[r + 1][c + 2];
+            const int bl = s_t[r + 2][c], bc = s_t[r + 2][c + 1], br = s_t[r + 2][c + 2];
+            const int sx = (tr - tl) + 2 * (mr - ml) + (br - bl);
+            const int sy = (bl - tl) + 2 * (bc - tc) + (br - tr);
+            e = sx + sy;
+        }
+        s_e[r][c] = e;
+    }
+    __syncthreads();
+    for (int i = t; i < EH * DW; i += 256) {            // row max over 5 columns
+        const int r = i / DW, c = i - r * DW;
+        int m = s_e[r][c];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) m = max(m, s_e[r][c + k]);
+        s_h[r][c] = m;
+    }
+    __syncthreads();
+    for (int i = t; i < DH * DW; i += 256) {            // column max -> D at (y0-2+r, x0-2+c)
+        const int r = i / DW, c = i - r * DW;
+        int m = s_h[r][c];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) m = max(m, s_h[r + k][c]);
+        const int yy = y0 - 2 + r, xx = x0 - 2 + c;
+        s_d[r][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? m : INT_MAX;   // outside never wins the min
+    }
+    __syncthreads();
+    for (int i = t; i < DH * EM_TW; i += 256) {         // row min over 5 columns (reuses s_h)
+        const int r = i / EM_TW, c = i - r * EM_TW;
+        int m = s_d[r][c];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) m = min(m, s_d[r][c + k]);
+        s_h[r][c] = m;
+    }
+    __syncthreads();
+    double *dst = a.dst.at(plane);
+    for (int i = t; i < EM_TH * EM_TW; i += 256) {      // column min -> output
+        const int r = i / EM_TW, c = i - r * EM_TW;
+        const int yy = y0 + r, xx = x0 + c;
+        if (yy < H && xx < W) {
+            int m = s_h[r][c];
+#pragma unroll
+            for (int k = 1; k < 5; ++k) m = min(m, s_h[r + k][c]);
+            dst[(long long)yy * a.dst.pitch + xx] = (double)m;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -692,6 +692,27 @@ int lkflow_u8_to_f64_dev(lkflow_ctx *ctx, const unsigned char *src, double *dst,
     return LKFLOW_OK;
 }
 
+int lkflow_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *src, size_t src_ps, int n_planes, int rows,
+                           int cols, size_t src_step_bytes, int thresh, double *dst, size_t dst_ps,
+                           size_t dst_step_bytes, void *stream)
+{
+    if (!ctx || !src || !dst || rows < 1 || cols < 1 || n_planes < 1) return LKFLOW_E_ARG;
+    if (src_step_bytes < (size_t)cols || dst_step_bytes < (size_t)cols * 8 || dst_step_bytes % 8 || dst_ps % 8)
+        return LKFLOW_E_ARG;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    lk::EdgeArgs a{};
+    a.src = src; a.src_plane = (long long)src_ps; a.src_pitch = (long long)src_step_bytes;
+    a.dst = Planes{dst, (long long)(dst_ps / 8), (long long)(dst_step_bytes / 8)};
+    a.H = rows; a.W = cols; a.thresh = thresh;
+    a.gx = (cols + lk::EM_TW - 1) / lk::EM_TW; a.gy = (rows + lk::EM_TH - 1) / lk::EM_TH;
+    const long long n = (long long)a.gx * a.gy * n_planes;
+    if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
+    hipLaunchKernelGGL(lk::edge_map_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
 int lkflow_flow_centroid_f64_dev(lkflow_ctx *ctx, const double *U, const double *V, size_t uv_ps, int n_pairs,
                                  int rows, int cols, size_t uv_step_bytes, double thresh, double *out,
                                  void *stream)

@@ -65,6 +65,7 @@ SIGNATURES = {
     "lkflow_warp_f64_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _vp, _vp, _sz, _sz, _vp, _vp,
                                  _sz, _sz, _vp]),
     "lkflow_u8_to_f64_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "lkflow_edge_map_u8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _i, _vp, _sz, _sz, _vp]),
     "lkflow_flow_centroid_f64_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _vp, _vp]),
 }
 
@@ -328,6 +329,20 @@ class Context:
         self._chk(lib().lkflow_u8_to_f64_dev(self._h, src.data_ptr(), dst.data_ptr(), src.numel(),
                                              _stream_ptr(stream)))
         return dst
+
+    def edge_map(self, diff_u8, thresh=10, stream=None):
+        """[N,H,W] uint8 frame differences -> [N,H,W] float64 edge images (ParallelVideoPyr.cpp:803-813:
+        threshold TOZERO, Sobel x + Sobel y, dilate x2, erode x2) = the hot call's inputs."""
+        torch = _torch()
+        assert diff_u8.is_cuda and diff_u8.dtype == torch.uint8 and diff_u8.stride(-1) == 1
+        if diff_u8.dim() == 2:
+            diff_u8 = diff_u8.unsqueeze(0)
+        N, H, W = diff_u8.shape
+        out = torch.empty((N, H, W), dtype=torch.float64, device=diff_u8.device)
+        self._chk(lib().lkflow_edge_map_u8_dev(self._h, diff_u8.data_ptr(), diff_u8.stride(0), N, H, W,
+                                               diff_u8.stride(1), int(thresh), out.data_ptr(),
+                                               out.stride(0) * 8, out.stride(1) * 8, _stream_ptr(stream)))
+        return out
 
     def flow_centroid(self, U, V, thresh=20.0, stream=None):
         """[P,H,W] flows -> [P,3] tensor (count, sum_x, sum_y) of pixels with |flow| >= thresh

@@ -394,3 +394,50 @@ void lko_flow_centroid(const double *u, const double *v, int rows, int cols, dou
         }
     *count = c; *sum_x = sx; *sum_y = sy;
 }
+
+/*
+ * ParallelVideoPyr.cpp:803-813.  OpenCV 2.4 semantics restated:
+ *   threshold(.., THRESH_TOZERO): v > thresh ? v : 0                                   (thresh.cpp)
+ *   Sobel(src, dst, CV_64F, 1, 0): sepFilter2D with kx = [-1 0 1], ky = [1 2 1]; (0, 1): kx = [1 2 1],
+ *     ky = [-1 0 1]; correlation, BORDER_DEFAULT = REFLECT_101                       (deriv.cpp)
+ *   dilate / erode(src, dst, Mat(), Point(-1,-1), 2): 3x3 rectangle, two iterations, BORDER_CONSTANT with
+ *     morphologyDefaultBorderValue() = "pixels outside the image never win"           (morph.cpp)
+ */
+static void morph3x3(const double *src, int rows, int cols, int is_dilate, double *dst)
+{
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            double m = src[(size_t)y * cols + x];
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int yy = y + dy, xx = x + dx;
+                    if (yy < 0 || yy >= rows || xx < 0 || xx >= cols) continue;
+                    double v = src[(size_t)yy * cols + xx];
+                    if (is_dilate ? v > m : v < m) m = v;
+                }
+            dst[(size_t)y * cols + x] = m;
+        }
+}
+
+void lko_edge_map_u8(const unsigned char *diff, int rows, int cols, int thresh, double *out)
+{
+    size_t n = (size_t)rows * cols;
+    double *t = (double *)malloc(n * sizeof(double)), *e = (double *)malloc(n * sizeof(double));
+    for (size_t i = 0; i < n; ++i) t[i] = diff[i] > thresh ? (double)diff[i] : 0.0;   /* :803 */
+    for (int y = 0; y < rows; ++y) {                                                   /* :808-811 */
+        int ym = r101(y - 1, rows), yp = r101(y + 1, rows);
+        for (int x = 0; x < cols; ++x) {
+            int xm = r101(x - 1, cols), xp = r101(x + 1, cols);
+#define T(yy, xx) t[(size_t)(yy) * cols + (xx)]
+            double sx = (T(ym, xp) - T(ym, xm)) + 2 * (T(y, xp) - T(y, xm)) + (T(yp, xp) - T(yp, xm));
+            double sy = (T(yp, xm) - T(ym, xm)) + 2 * (T(yp, x) - T(ym, x)) + (T(yp, xp) - T(ym, xp));
+#undef T
+            e[(size_t)y * cols + x] = sx + sy;             /* exact integers: summation order is irrelevant */
+        }
+    }
+    morph3x3(e, rows, cols, 1, t);                          /* :812 dilate, iterations = 2 */
+    morph3x3(t, rows, cols, 1, e);
+    morph3x3(e, rows, cols, 0, t);                          /* :813 erode, iterations = 2 */
+    morph3x3(t, rows, cols, 0, out);
+    free(t); free(e);
+}

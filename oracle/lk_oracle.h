@@ -59,6 +59,11 @@ void lko_u8_to_f64(const unsigned char *src, long n, double *dst);
 void lko_flow_centroid(const double *u, const double *v, int rows, int cols, double thresh,
                        long long *count, double *sum_x, double *sum_y);
 
+/* ParallelVideoPyr.cpp:803-813 -- the step that PRODUCES the hot call's CV_64F inputs from the 8-bit
+ * frame difference: threshold(diff, 10, 255, THRESH_TOZERO); Sobel x + Sobel y (CV_64F, 3x3, reflect-101);
+ * dilate x2; erode x2 (3x3 rect, outside pixels ignored).  All values are exact integers. */
+void lko_edge_map_u8(const unsigned char *diff, int rows, int cols, int thresh, double *out);
+
 #ifdef __cplusplus
 }
 #endif

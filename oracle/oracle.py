@@ -66,6 +66,8 @@ def lib():
         L.lko_flow_centroid.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                         ctypes.POINTER(ctypes.c_longlong), _dp, _dp]
         L.lko_flow_centroid.restype = None
+        L.lko_edge_map_u8.argtypes = [ctypes.POINTER(ctypes.c_ubyte), ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp]
+        L.lko_edge_map_u8.restype = None
         _LIB = L
     return _LIB
 
@@ -154,6 +156,15 @@ def u8_to_f64(a):
     a = np.ascontiguousarray(a, dtype=np.uint8)
     out = np.empty(a.shape, dtype=np.float64)
     lib().lko_u8_to_f64(a.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), a.size, _p(out))
+    return out
+
+
+def edge_map_u8(diff, thresh=10):
+    diff = np.ascontiguousarray(diff, dtype=np.uint8)
+    assert diff.ndim == 2
+    out = np.empty(diff.shape, dtype=np.float64)
+    lib().lko_edge_map_u8(diff.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), diff.shape[0], diff.shape[1],
+                          int(thresh), _p(out))
     return out
 
 

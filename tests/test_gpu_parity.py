@@ -334,3 +334,17 @@ def test_full_size_8k_w31_march_equals_per_pixel(gpu_ctx, lkflow, torch):
         gpu_ctx.set_option(lkflow.LKFLOW_OPT_IMPL, 0)
     torch.cuda.synchronize()
     assert (u - un).abs().max().item() <= TOL and (v - vn).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("shape", [(448, 640), (1, 1), (2, 3), (5, 200), (37, 9), (1080, 1080)])
+def test_edge_map_bit_exact(gpu_ctx, oracle, torch, table_u8, shape):
+    """ParallelVideoPyr.cpp:803-813 (threshold TOZERO, Sobel x+y, dilate x2, erode x2): exact integers."""
+    rng = np.random.default_rng(shape[0] * 31 + shape[1])
+    if shape == (448, 640):
+        d = np.stack([table_u8[0], table_u8[1]])
+    else:
+        d = rng.integers(0, 256, (2,) + shape).astype(np.uint8)
+        d[0, : shape[0] // 2] = 3                      # a region below the threshold -> exactly flat
+    got = host(gpu_ctx.edge_map(dev(torch, d), 10))
+    for k in range(2):
+        assert np.array_equal(got[k], oracle.edge_map_u8(d[k], 10))

@@ -125,3 +125,30 @@ def test_flow_centroid(oracle):
     u[2, 3] = 25.0; v[4, 6] = -30.0; u[0, 0] = 19.999
     c, sx, sy = oracle.flow_centroid(u, v, 20.0)
     assert (c, sx, sy) == (2, 9.0, 6.0)
+
+
+def test_edge_map_oracle_matches_direct_5x5_formulation(oracle):
+    """ParallelVideoPyr.cpp:803-813: two 3x3 dilations (erosions) with outside pixels ignored == one 5x5
+    max (min); Sobel x + Sobel y with reflect-101; threshold TOZERO.  Brute-force NumPy cross-check."""
+    rng = np.random.default_rng(0)
+    d = rng.integers(0, 256, (20, 30)).astype(np.uint8)
+    got = oracle.edge_map_u8(d, 10)
+    t = np.where(d > 10, d, 0).astype(np.float64)
+    H, W = t.shape
+
+    def r(i, n):
+        while i < 0 or i >= n:
+            i = -i if i < 0 else 2 * n - 2 - i
+        return i
+    e = np.zeros_like(t)
+    for y in range(H):
+        for x in range(W):
+            ym, yp, xm, xp = r(y - 1, H), r(y + 1, H), r(x - 1, W), r(x + 1, W)
+            sx = (t[ym, xp] - t[ym, xm]) + 2 * (t[y, xp] - t[y, xm]) + (t[yp, xp] - t[yp, xm])
+            sy = (t[yp, xm] - t[ym, xm]) + 2 * (t[yp, x] - t[ym, x]) + (t[yp, xp] - t[ym, xp])
+            e[y, x] = sx + sy
+
+    def mm(a, f):
+        return np.array([[f(a[max(0, y - 2):y + 3, max(0, x - 2):x + 3]) for x in range(W)] for y in range(H)])
+    assert np.array_equal(got, mm(mm(e, np.max), np.min))
+    assert not oracle.edge_map_u8(np.full((9, 9), 7, np.uint8), 10).any()      # below threshold -> flat -> 0
