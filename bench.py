@@ -27,6 +27,8 @@ CONFIGS = {
     "4k": (3840, 2160, 5, 21, 8),
     "8k": (7680, 4320, 5, 31, 4),
     "pacman": (240, 160, 3, 15, 244),
+    # the reference's own shipped loop: 1080x1080 CV_64F, getMaxLayer = 4 levels, 3x3 (ParallelVideoPyr.cpp:782,831)
+    "webcam": (1080, 1080, 4, 3, 48),
 }
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 
