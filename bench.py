@@ -87,7 +87,7 @@ def cpu_baseline(cols, rows, levels, win, budget_s=20.0):
             O.omp_coarse_to_fine(a, b, levels, win, mode)
             n += 1
             dt = time.perf_counter() - t0
-            if dt > budget_s / 2 or n >= 8:
+            if dt > budget_s * (0.6 if mode == 0 else 0.3) or n >= 96:
                 break
         res[mode] = (n * rows * cols / dt / 1e6, n, dt, name)
     cores = O.omp_lib().lkc_num_threads()

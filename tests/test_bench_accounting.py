@@ -1,0 +1,18 @@
+"""CPU suite: bench.py's roofline accounting reproduces SURVEY.md 8(d)'s per-unit figures."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_algorithmic_bytes_match_survey_figures():
+    import bench
+    # B_alg = sum_{l>=1} 2s(N_{l-1}+N_l) + sum_l s(4N_l + 2N_{l+1}),  s = 8
+    b = bench.algorithmic_bytes_per_pair(1920, 1080, 3)
+    assert b == 149_299_200 and abs(b / (1920 * 1080) - 72.0) < 1e-9          # 72.0 B/px, 149.3 MB per 1080p pair
+    assert abs(bench.algorithmic_bytes_per_pair(3840, 2160, 5) / (3840 * 2160) - 74.5) < 0.05   # 617.9 MB
+    assert abs(bench.algorithmic_bytes_per_pair(1080, 1080, 4) / (1080 * 1080) - 74.0) < 0.05
+    # dominant kernel (LK at level 0): read 2 images + coarse u,v, write u,v = 36 B/px
+    assert bench.lk0_bytes_per_pair(1920, 1080, 3) == 36 * 1920 * 1080
+    assert set(bench.CONFIGS) >= {"1080p", "4k", "8k", "pacman", "webcam"}
