@@ -73,6 +73,36 @@ def measured_traffic(kernel_prefix, cols, rows, pairs):
     return None
 
 
+def pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, device, world, chunks=4, steps=10):
+    """Extra, NOT the headline: the same batch split over `chunks` contexts/streams that run
+    unsynchronised (how a video pipeline keeps several chunks in flight).  Kernel tails of one chunk are
+    back-filled by another chunk's kernels, so whole-job throughput is higher, while each LK launch takes
+    longer under the contention -- which is why `value`/`roofline` above are taken single-stream."""
+    P, rows, cols = prev.shape
+    bounds = [P * k // chunks for k in range(chunks + 1)]
+    ctxs = [lkf.Context(device) for _ in range(chunks)]
+    streams = [torch.cuda.Stream() for _ in range(chunks)]
+    for k in range(chunks):
+        ctxs[k].reserve(rows, cols, levels, bounds[k + 1] - bounds[k])
+
+    def step():
+        for k in range(chunks):
+            sl = slice(bounds[k], bounds[k + 1])
+            ctxs[k].compute_batch(prev[sl], nxt[sl], levels, win, out=(U[sl], V[sl]), stream=streams[k])
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for c in ctxs:
+        c.close()
+    return {"chunks_in_flight": chunks, "steps": steps, "rank0_value": round(P * rows * cols * steps / dt / 1e6, 2),
+            "unit": "Mpixels/s", "note": "rank 0 only, extra measurement after the timed region"}
+
+
 def cpu_baseline(cols, rows, levels, win, budget_s=20.0):
     """Times oracle/lk_cpu_omp.c (the restated ParallelVideoPyr.cpp CPU path) on this host."""
     import synth
@@ -109,6 +139,9 @@ def main():
     ap.add_argument("--config", default="1080p", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time of every stage")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="split each step's batch over this many contexts/streams that run unsynchronised "
+                         "(kernel tails of one chunk are back-filled by another chunk's kernels)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph and replay it (launch-bound small batches); "
                          "the per-kernel HIP-event roofline is then taken from a separate eager pass")
@@ -142,11 +175,28 @@ def main():
     U = torch.empty_like(prev)
     V = torch.empty_like(prev)
     ctx = lkf.Context(local_rank)
-    ctx.reserve(rows, cols, levels, P)
     stream = torch.cuda.current_stream()
+    K = max(1, min(args.inflight, P))
+    if K == 1:
+        ctx.reserve(rows, cols, levels, P)
 
-    def eager_step():
-        ctx.compute_batch(prev, nxt, levels, win, out=(U, V), stream=stream)
+        def eager_step():
+            ctx.compute_batch(prev, nxt, levels, win, out=(U, V), stream=stream)
+    else:
+        # K independent chunks in flight, one context + stream each ("one HIP stream per
+        # in-flight pair"); chunk 0 runs on `ctx` so that its LK launches carry the roofline events
+        assert not args.graph, "--graph and --inflight are separate experiments"
+        bounds = [P * k // K for k in range(K + 1)]
+        ctxs = [ctx] + [lkf.Context(local_rank) for _ in range(K - 1)]
+        streams = [torch.cuda.Stream() for _ in range(K)]
+        for k in range(K):
+            ctxs[k].reserve(rows, cols, levels, bounds[k + 1] - bounds[k])
+            streams[k].wait_stream(stream)
+
+        def eager_step():
+            for k in range(K):
+                sl = slice(bounds[k], bounds[k + 1])
+                ctxs[k].compute_batch(prev[sl], nxt[sl], levels, win, out=(U[sl], V[sl]), stream=streams[k])
 
     step = eager_step
     graph = None
@@ -202,7 +252,8 @@ def main():
         value = px_per_step * args.steps / dt / 1e6
         lk0_ms, lk0_n = prof[(lkf.LKFLOW_STAGE_LK, 0)]
         lk0_avg_s = lk0_ms / lk0_n / 1e3
-        lk0_bytes = lk0_bytes_per_pair(cols, rows, levels) * P
+        pairs_per_launch = P if K == 1 else P // K          # events are on chunk 0's context
+        lk0_bytes = lk0_bytes_per_pair(cols, rows, levels) * pairs_per_launch
         achieved = lk0_bytes / lk0_avg_s
         b_alg = algorithmic_bytes_per_pair(cols, rows, levels)
         path_achieved = b_alg * P * args.steps / dt          # per GPU
@@ -226,6 +277,7 @@ def main():
                 "pairs_per_step_per_gpu": P,
                 "parallelism": f"frame-pair sharding x{world} (no data-path collective)",
                 "launch": "hip-graph replay" if args.graph else "eager",
+                "chunks_in_flight": K,
             },
             "frame_pairs_per_s": round(P * world * args.steps / dt, 2),
             "roofline": {
@@ -237,10 +289,11 @@ def main():
                 "frac": round(achieved / HBM_PEAK, 4),
                 # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, gfx950 x2
                 # FETCH_SIZE correction applied; committed under profiles/), null if not collected
-                "traffic": measured_traffic(f"lk::lk_march3_kernel<{win}, 256, true>", cols, rows, P),
+                "traffic": measured_traffic(f"lk::lk_march3_kernel<{win}, 256, true>", cols, rows, pairs_per_launch),
                 "algorithmic_bytes_per_launch": lk0_bytes,
                 "avg_launch_ms": round(lk0_avg_s * 1e3, 4),
                 "launches_timed": lk0_n,
+                "pairs_per_launch": pairs_per_launch,
             },
             "path_roofline": {
                 "algorithmic_bytes_per_pair": b_alg,
@@ -254,6 +307,8 @@ def main():
                                         for (s, l), (ms, n) in sorted(prof.items())}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cols, rows, levels, win)
+        if K == 1 and not args.graph and P >= 8:
+            out["pipelined"] = pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, local_rank, world)
         print(json.dumps(out), flush=True)
 
     ctx.close()
