@@ -73,7 +73,7 @@ def measured_traffic(kernel_prefix, cols, rows, pairs):
     return None
 
 
-def pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, device, world, chunks=4, steps=10):
+def pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, device, world, chunks=4, steps=20):
     """Extra, NOT the headline: the same batch split over `chunks` contexts/streams that run
     unsynchronised (how a video pipeline keeps several chunks in flight).  Kernel tails of one chunk are
     back-filled by another chunk's kernels, so whole-job throughput is higher, while each LK launch takes
@@ -89,7 +89,7 @@ def pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, device, world, chun
         for k in range(chunks):
             sl = slice(bounds[k], bounds[k + 1])
             ctxs[k].compute_batch(prev[sl], nxt[sl], levels, win, out=(U[sl], V[sl]), stream=streams[k])
-    for _ in range(2):
+    for _ in range(5):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -305,10 +305,10 @@ def main():
             names = {0: "pyrdown", 1: "warp", 2: "lk"}
             out["stage_ms_per_step"] = {f"{names[s]}_L{l}": round(ms / args.steps, 4)
                                         for (s, l), (ms, n) in sorted(prof.items())}
+        if world == 1 and K == 1 and not args.graph and P >= 8:
+            out["pipelined"] = pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, local_rank, world)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cols, rows, levels, win)
-        if K == 1 and not args.graph and P >= 8:
-            out["pipelined"] = pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, local_rank, world)
         print(json.dumps(out), flush=True)
 
     ctx.close()
