@@ -42,7 +42,12 @@ def goldens():
 
 @pytest.fixture(scope="session")
 def lkflow():
+    """The ctypes binding; builds liblkflow.so first if it is missing (the .so is git-ignored, so a fresh
+    checkout has none -- hipcc cross-compiles gfx950 without a GPU, about a minute)."""
     import lkflow_amd
+    if not os.path.exists(lkflow_amd.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build_hip()
     return lkflow_amd
 
 
