@@ -160,11 +160,13 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         const double na0 = I1l[rn], na1 = I1c[rn], nb0 = I2l[rn], nb1 = I2c[rn];
         const int y = yy - R;                                   // output row of this iteration
         const bool out_row = i >= 2 * R;
-        // the NEXT coarse row of the "+= pyrUp" term is fetched during odd output rows (slot 0 of the
-        // carried rows is dead there) and turned into the new slot in this row's epilogue
+        // the NEXT coarse row of the "+= pyrUp" term is turned into the new carried slot in the epilogue of
+        // odd output rows (slot 0 is dead there).  Its three taps per plane are fetched at the top of EVERY
+        // row, unconditionally: with a conditional fetch the compiler's s_waitcnt before the products
+        // (which only need the row prefetched one iteration ago) counts the minimum over both paths and
+        // ends up waiting for the image loads issued just above on every odd row.
         [[maybe_unused]] double uA = 0, uB = 0, uC = 0, vA = 0, vB = 0, vC = 0;
-        const bool up_pref = HAS_UP && out_row && (y & 1) != 0;
-        if (up_pref) {
+        if (HAS_UP) {
             const int sr = up_srow(((y + 1) >> 1) + 1);
             const double *ru = CU + sr * cpu, *rv = CV + sr * cpv;
             uA = ru[us.jm]; uB = ru[us.jc]; uC = ru[us.jp];
