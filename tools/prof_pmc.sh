@@ -19,7 +19,7 @@ PASSES=(
 )
 i=0
 for P in "${PASSES[@]}"; do
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python3 $R/bench.py --no-extras "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
   i=$((i+1))
 done
 python3 $R/tools/pmc_summary.py $OUT $R/gpurun_out/pmc_${TAG}_traffic.json > $R/gpurun_out/pmc_$TAG.txt 2>&1
