@@ -119,21 +119,14 @@ __device__ __forceinline__ double pyrup_at(const double *c, long long pitch, int
     return (r0 + r1 * 6 + r2) * (1.0 / 64);
 }
 
-// cvRound as OpenCV 2.4 compiles it on x86-64 (cvtsd2si): round-half-even; NaN / out of range ->
-// 0x80000000.
-__device__ __forceinline__ int cv_round(double v)
-{
-    if (!(v > -2147483648.5 && v < 2147483647.5)) return INT_MIN;
-    return __double2int_rn(v);
-}
-
 __device__ __forceinline__ int sat_short(int v)
 {
     return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
 }
 
-// cvRound(t) for a FLOAT argument (the map coordinate * 32): float -> double is exact, so rounding the
-// float half-to-even gives the same integer as cv_round((double)t), at 32-bit instruction cost.
+// cvRound(t) as OpenCV 2.4 compiles it on x86-64 (cvtsd2si: round-half-even; NaN / out of range ->
+// 0x80000000), for the FLOAT argument remap passes (map coordinate * 32): float -> double is exact, so
+// rounding the float half-to-even gives the same integer as rounding its double image, at 32-bit cost.
 __device__ __forceinline__ int cv_round_f(float t)
 {
     if (!(fabsf(t) < 2147483648.0f)) return INT_MIN;   // NaN / out of range -> 0x80000000
