@@ -166,5 +166,26 @@ __device__ __forceinline__ double remap_bilinear(const double *src, int pitch, i
     return v0 * (double)w0 + v1 * (double)w1 + v2 * (double)w2 + v3 * (double)w3;
 }
 
+// Raw buffer access (gfx9 V#: stride 0, offset = VGPR byte offset + SGPR byte offset, range-checked
+// against num_records).  The per-thread column offset is loop-invariant and the row offset is
+// wave-uniform, so a row access costs NO vector ALU address arithmetic.
+typedef unsigned int lk_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const double *base, long long bytes)
+{
+    const unsigned n = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const lk_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, int voff, int soff, double d)
+{
+    lk_u2 v;
+    v.x = (unsigned)__double2loint(d);
+    v.y = (unsigned)__double2hiint(d);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
 
 }  // namespace lk

@@ -156,7 +156,13 @@ struct WarpArgs {
     int th;           // rows per block (even)
 };
 
-__global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
+#ifndef LK_WARP_VARIANT
+#define LK_WARP_VARIANT 2
+#endif
+#ifndef LK_WARP_WAVES
+#define LK_WARP_WAVES 1
+#endif
+__global__ __launch_bounds__(256, LK_WARP_WAVES) void warp_kernel(WarpArgs a)
 {
     const unsigned n = gridDim.x;
     unsigned tile = xcd_tile_id(blockIdx.x, n);
@@ -168,47 +174,68 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     const int y0 = by * a.th, y1 = min(y0 + a.th, H);
     if (x >= W) return;
 
-    // per-thread pyrUp column selectors (see pyrup_h())
+    // per-thread pyrUp column selectors (see pyrup_h()); tap positions as byte offsets
     const int j = x >> 1;
-    const int jm = j > 0 ? j - 1 : 0, jp = j < Wc - 1 ? j + 1 : Wc - 1;
+    const int jm8 = (j > 0 ? j - 1 : 0) * 8, jc8 = j * 8, jp8 = (j < Wc - 1 ? j + 1 : Wc - 1) * 8;
     const bool single = Wc == 1, left = j == 0, right = j == Wc - 1, odd = (x & 1) != 0;
-    const double mB = single ? 8.0 : (right ? 7.0 : 6.0);
-    const double wA = (single || left) ? 0.0 : 1.0;
-    const double wC = (single || right) ? 0.0 : (left ? 2.0 : 1.0);
+    // (weights kept as floats -- exact small integers -- to stay within 64 VGPRs = 8 waves per SIMD)
+    const float mBf = single ? 8.0f : (right ? 7.0f : 6.0f);
+    const float wAf = (single || left) ? 0.0f : 1.0f;
+    const float wCf = (single || right) ? 0.0f : (left ? 2.0f : 1.0f);
     const bool dup = single || right;
-    const double *CU = a.cu.at(p), *CV = a.cv.at(p);
-    const int cpu = (int)a.cu.pitch, cpv = (int)a.cv.pitch;
-    auto srow = [&](int k) { return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };   // r101(2k,2Hc)/2
-    auto htap = [&](const double *r) __attribute__((always_inline)) -> double {
-        const double A = r[jm], B = r[j], C = r[jp];
-        const double ev = (A * wA + B * mB) + C * wC;
+    // coarse flow rows and output rows through buffer descriptors based at the strip's first row: the
+    // column byte offset is loop-invariant and the row offset wave-uniform (no vector address arithmetic)
+    const int i0 = y0 >> 1;                                 // y0 is even
+    const int crow_lo = max(i0 - 1, 0);
+    const int cpub = (int)a.cu.pitch * 8, cpvb = (int)a.cv.pitch * 8;
+    const __amdgpu_buffer_rsrc_t rCU = buf_rsrc(a.cu.at(p) + (long long)crow_lo * a.cu.pitch, ((long long)(Hc - 1 - crow_lo) * a.cu.pitch + Wc) * 8);
+    const __amdgpu_buffer_rsrc_t rCV = buf_rsrc(a.cv.at(p) + (long long)crow_lo * a.cv.pitch, ((long long)(Hc - 1 - crow_lo) * a.cv.pitch + Wc) * 8);
+    auto srow = [&](int k) { return (k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k)) - crow_lo; };   // r101(2k,2Hc)/2
+    auto htap = [&](__amdgpu_buffer_rsrc_t r, int so) __attribute__((always_inline)) -> double {
+        const double A = buf_ld(r, jm8, so), B = buf_ld(r, jc8, so), C = buf_ld(r, jp8, so);
+        const double ev = (A * (double)wAf + B * (double)mBf) + C * (double)wCf;
         const double od = (B + (dup ? B : C)) * 4;
         return odd ? od : ev;
     };
 
     const double *I1 = a.img1.at(p), *I2 = a.img2.at(p);
-    const int ip = (int)a.img1.pitch, op1 = (int)a.out1.pitch, op2 = (int)a.out2.pitch;
-    double *o1 = a.out1.at(p) + y0 * op1 + x;
-    double *o2 = a.out2.at(p) + y0 * op2 + x;
+    const int ip = (int)a.img1.pitch, op1b = (int)a.out1.pitch * 8, op2b = (int)a.out2.pitch * 8;
+    const __amdgpu_buffer_rsrc_t rO1 = buf_rsrc(a.out1.at(p) + (long long)y0 * a.out1.pitch, ((long long)(y1 - 1 - y0) * a.out1.pitch + W) * 8);
+    const __amdgpu_buffer_rsrc_t rO2 = buf_rsrc(a.out2.at(p) + (long long)y0 * a.out2.pitch, ((long long)(y1 - 1 - y0) * a.out2.pitch + W) * 8);
+    const int x8 = x * 8;
     const float xf = (float)x;
 
-    int i = y0 >> 1;                                        // y0 is even
-    double hu0 = htap(CU + srow(i - 1) * cpu), hu1 = htap(CU + srow(i) * cpu);
-    double hv0 = htap(CV + srow(i - 1) * cpv), hv1 = htap(CV + srow(i) * cpv);
+    int i = i0;
+    double hu0 = htap(rCU, srow(i - 1) * cpub), hu1 = htap(rCU, srow(i) * cpub);
+    double hv0 = htap(rCV, srow(i - 1) * cpvb), hv1 = htap(rCV, srow(i) * cpvb);
     for (int y = y0; y < y1; y += 2, ++i) {
-        const double hu2 = htap(CU + srow(i + 1) * cpu), hv2 = htap(CV + srow(i + 1) * cpv);
+        const double hu2 = htap(rCU, srow(i + 1) * cpub), hv2 = htap(rCV, srow(i + 1) * cpvb);
         const double upu0 = (hu0 + hu1 * 6 + hu2) * (1.0 / 64), upu1 = ((hu1 + hu2) * 4) * (1.0 / 64);
         const double upv0 = (hv0 + hv1 * 6 + hv2) * (1.0 / 64), upv1 = ((hv1 + hv2) * 4) * (1.0 / 64);
         // map build (ParallelVideoPyr.cpp:674-678), float32 arithmetic
         const float hx0 = (float)upu0 / 2, hy0 = (float)upv0 / 2, hx1 = (float)upu1 / 2, hy1 = (float)upv1 / 2;
         const float yf0 = (float)y, yf1 = (float)(y + 1);
+        const int so1 = (y - y0) * op1b, so2 = (y - y0) * op2b;
+#if LK_WARP_VARIANT == 0
+        buf_st(rO1, x8, so1, remap_bilinear(I1, ip, H, W, xf + hx0, yf0 + hy0));
+        buf_st(rO2, x8, so2, remap_bilinear(I2, ip, H, W, xf - hx0, yf0 - hy0));
+        buf_st(rO1, x8, so1 + op1b, remap_bilinear(I1, ip, H, W, xf + hx1, yf1 + hy1));   // H is even: row y+1 exists
+        buf_st(rO2, x8, so2 + op2b, remap_bilinear(I2, ip, H, W, xf - hx1, yf1 - hy1));
+#elif LK_WARP_VARIANT == 1
+        const double a0 = remap_bilinear(I1, ip, H, W, xf + hx0, yf0 + hy0);
+        const double b0 = remap_bilinear(I2, ip, H, W, xf - hx0, yf0 - hy0);
+        buf_st(rO1, x8, so1, a0); buf_st(rO2, x8, so2, b0);
+        const double a1 = remap_bilinear(I1, ip, H, W, xf + hx1, yf1 + hy1);
+        const double b1 = remap_bilinear(I2, ip, H, W, xf - hx1, yf1 - hy1);
+        buf_st(rO1, x8, so1 + op1b, a1); buf_st(rO2, x8, so2 + op2b, b1);
+#else
         const double a0 = remap_bilinear(I1, ip, H, W, xf + hx0, yf0 + hy0);
         const double b0 = remap_bilinear(I2, ip, H, W, xf - hx0, yf0 - hy0);
         const double a1 = remap_bilinear(I1, ip, H, W, xf + hx1, yf1 + hy1);
         const double b1 = remap_bilinear(I2, ip, H, W, xf - hx1, yf1 - hy1);
-        o1[0] = a0; o2[0] = b0;
-        o1[op1] = a1; o2[op2] = b1;                         // H is even: row y+1 exists
-        o1 += 2 * op1; o2 += 2 * op2;
+        buf_st(rO1, x8, so1, a0); buf_st(rO2, x8, so2, b0);
+        buf_st(rO1, x8, so1 + op1b, a1); buf_st(rO2, x8, so2 + op2b, b1);
+#endif
         hu0 = hu1; hu1 = hu2; hv0 = hv1; hv1 = hv2;
     }
 }

@@ -29,46 +29,39 @@ __device__ __forceinline__ double dpp_swap1(double v)
     return __hiloint2double(shi, slo);
 }
 
-// Horizontal cv::pyrUp tap of one coarse row for ONE fine column (branch-free form of pyrup_h()):
-//   even x: (A + B*mB) + C2   interior A=c[j-1] mB=6 C2=c[j+1] | left A=0 mB=6 C2=c[1]*2
-//                             | right A=c[W-2] mB=7 C2=0 | single A=0 mB=8 C2=0
-//   odd x : (B + Co)*4        interior/left Co=c[j+1] | right/single Co=B  ((B+B)*4 == B*8 exactly)
+// Horizontal cv::pyrUp tap of one coarse row for ONE fine column, as three per-lane weights:
+//   h = (A*wA + B*wB) + C*wC   with A = c[j-1], B = c[j], C = c[j+1] (clamped indices)
+//   even x: interior (1,6,1) | left (0,6,2) | right (1,7,0) | single (0,8,0)
+//   odd  x: interior/left (0,4,4) | right/single (0,8,0)
+// Every weight on A and C is 0 or a power of two, so A*wA and C*wC are exact and the two FMAs round
+// exactly where pyrup_h()'s additions round ((B+C)*4 == B*4 + C*4 bit for bit).
 struct UpSel1 {
-    int jm, jc, jp;
-    double mB;
-    bool odd, keepA, dup;
-    int cmode;  // C2 = 0 (0), c[jp] (1), c[jp]*2 (2)
+    int jm, jc, jp;         // BYTE offsets of the three taps inside a coarse row
+    double wA, wB, wC;
 };
 __device__ __forceinline__ UpSel1 make_upsel1(int x, int Wc)
 {
     UpSel1 s;
     int j = x >> 1;
     j = j < 0 ? 0 : (j > Wc - 1 ? Wc - 1 : j);
-    s.jc = j;
-    s.jm = j > 0 ? j - 1 : 0;
-    s.jp = j < Wc - 1 ? j + 1 : Wc - 1;
-    const bool single = Wc == 1, left = j == 0, right = j == Wc - 1;
-    s.odd = (x & 1) != 0;
-    s.mB = single ? 8.0 : (right ? 7.0 : 6.0);
-    s.keepA = !(single || left);
-    s.cmode = (single || right) ? 0 : (left ? 2 : 1);
-    s.dup = single || right;
+    s.jc = j * 8;
+    s.jm = (j > 0 ? j - 1 : 0) * 8;
+    s.jp = (j < Wc - 1 ? j + 1 : Wc - 1) * 8;
+    const bool single = Wc == 1, left = j == 0, right = j == Wc - 1, odd = (x & 1) != 0;
+    if (odd) {
+        s.wA = 0.0;
+        s.wB = (single || right) ? 8.0 : 4.0;
+        s.wC = (single || right) ? 0.0 : 4.0;
+    } else {
+        s.wA = (single || left) ? 0.0 : 1.0;
+        s.wB = single ? 8.0 : (right ? 7.0 : 6.0);
+        s.wC = (single || right) ? 0.0 : (left ? 2.0 : 1.0);
+    }
     return s;
-}
-__device__ __forceinline__ double pyrup_h1v(double A, double B, double C, const UpSel1 &s);
-__device__ __forceinline__ double pyrup_h1(const double *c, const UpSel1 &s)
-{
-    return pyrup_h1v(c[s.jm], c[s.jc], c[s.jp], s);
 }
 __device__ __forceinline__ double pyrup_h1v(double A, double B, double C, const UpSel1 &s)
 {
-    // branch-free: both parities are evaluated, the lane's own is selected (odd/even lanes alternate,
-    // so a branch would execute both sides anyway)
-    const double A1 = s.keepA ? A : 0.0;
-    const double C2 = s.cmode == 2 ? C * 2 : (s.cmode == 1 ? C : 0.0);
-    const double ev = (A1 + B * s.mB) + C2;
-    const double od = (B + (s.dup ? B : C)) * 4;
-    return s.odd ? od : ev;
+    return __builtin_fma(C, s.wC, __builtin_fma(A, s.wA, B * s.wB));
 }
 
 template <int WIN, int TX, bool HAS_UP>
@@ -90,8 +83,14 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
     const bool col_in = x >= 0 && x < W;
     const int xc = min(max(x, 0), W - 1);
     const int xl = r101(xc - 1, W);
-    const double *I1c = a.i1.at(pair) + xc, *I2c = a.i2.at(pair) + xc;   // own column
-    const double *I1l = a.i1.at(pair) + xl, *I2l = a.i2.at(pair) + xl;   // left derivative tap
+    // buffer descriptors based at the first row the tile can touch (so that 32-bit offsets suffice for
+    // any plane size); per-thread byte offsets of the own column and of the left derivative tap
+    const int row_lo = (H <= R + 1) ? 0 : max(y0 - R - 1, 0);
+    const long long img_bytes = ((long long)(H - 1 - row_lo) * pitch + W) * 8;
+    const __amdgpu_buffer_rsrc_t rI1 = buf_rsrc(a.i1.at(pair) + (long long)row_lo * pitch, img_bytes);
+    const __amdgpu_buffer_rsrc_t rI2 = buf_rsrc(a.i2.at(pair) + (long long)row_lo * pitch, img_bytes);
+    const int vxc = xc * 8, vxl = xl * 8;
+    const int pitchb = pitch * 8;
     const bool is_out = t >= R && t < TX - R && x < W;
 
     // window decomposition in thread-index space: threads [t-R, t+R] = R pairs + one single
@@ -110,29 +109,37 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
     double pre[5] = {0, 0, 0, 0, 0};
 
     // previous row (pa*, pb*) and prefetched current row (ca*, cb*): [0] = left tap, [1] = own
-    int ro = r101(yy0 - 1, H) * pitch;
-    double pa0 = I1l[ro], pa1 = I1c[ro], pb0 = I2l[ro], pb1 = I2c[ro];
-    ro = r101(yy0, H) * pitch;
-    double ca0 = I1l[ro], ca1 = I1c[ro], cb0 = I2l[ro], cb1 = I2c[ro];
+    int ro = (r101(yy0 - 1, H) - row_lo) * pitchb;
+    double pa0 = buf_ld(rI1, vxl, ro), pa1 = buf_ld(rI1, vxc, ro), pb0 = buf_ld(rI2, vxl, ro), pb1 = buf_ld(rI2, vxc, ro);
+    ro = (r101(yy0, H) - row_lo) * pitchb;
+    double ca0 = buf_ld(rI1, vxl, ro), ca1 = buf_ld(rI1, vxc, ro), cb0 = buf_ld(rI2, vxl, ro), cb1 = buf_ld(rI2, vxc, ro);
 
     [[maybe_unused]] UpSel1 us{};
     [[maybe_unused]] double hu[3] = {0, 0, 0}, hv[3] = {0, 0, 0};   // carried coarse rows s(i-1),s(i),s(i+1)
     [[maybe_unused]] const int Hc = H >> 1;
-    [[maybe_unused]] const double *CU = nullptr, *CV = nullptr;
-    [[maybe_unused]] const int cpu = (int)a.cu.pitch, cpv = (int)a.cv.pitch;
+    [[maybe_unused]] const int cpub = (int)a.cu.pitch * 8, cpvb = (int)a.cv.pitch * 8;
+    [[maybe_unused]] const int crow_lo = max((y0 >> 1) - 1, 0);
     auto up_srow = [&](int k) { return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };
+    // (without HAS_UP the coarse descriptors are never used; they alias image 1 so that they are well-formed)
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rCU =
+        HAS_UP ? buf_rsrc(a.cu.at(pair) + (long long)crow_lo * a.cu.pitch, ((long long)(Hc - 1 - crow_lo) * a.cu.pitch + (W >> 1)) * 8) : rI1;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rCV =
+        HAS_UP ? buf_rsrc(a.cv.at(pair) + (long long)crow_lo * a.cv.pitch, ((long long)(Hc - 1 - crow_lo) * a.cv.pitch + (W >> 1)) * 8) : rI2;
     if (HAS_UP) {
         us = make_upsel1(xc, W >> 1);
-        CU = a.cu.at(pair);
-        CV = a.cv.at(pair);
         const int i0 = y0 >> 1;                                 // slots of the first output row
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            const int sr = up_srow(i0 - 1 + s);
-            hu[s] = pyrup_h1(CU + sr * cpu, us);
-            hv[s] = pyrup_h1(CV + sr * cpv, us);
+            const int sr = up_srow(i0 - 1 + s) - crow_lo;
+            hu[s] = pyrup_h1v(buf_ld(rCU, us.jm, sr * cpub), buf_ld(rCU, us.jc, sr * cpub), buf_ld(rCU, us.jp, sr * cpub), us);
+            hv[s] = pyrup_h1v(buf_ld(rCV, us.jm, sr * cpvb), buf_ld(rCV, us.jc, sr * cpvb), buf_ld(rCV, us.jp, sr * cpvb), us);
         }
     }
+    // outputs: descriptor based at the tile's first output row
+    const int upb = (int)a.u.pitch * 8, vpb = (int)a.v.pitch * 8;
+    const __amdgpu_buffer_rsrc_t rU = buf_rsrc(a.u.at(pair) + (long long)y0 * a.u.pitch, ((long long)(y1 - 1 - y0) * a.u.pitch + W) * 8);
+    const __amdgpu_buffer_rsrc_t rV = buf_rsrc(a.v.at(pair) + (long long)y0 * a.v.pitch, ((long long)(y1 - 1 - y0) * a.v.pitch + W) * 8);
+    const int vxo = x * 8;
 
     // One marched row at chunk position K (compile-time): the chunk loop below is unrolled WIN
     // times so that every ring access is a plain register (no dispatch, no copies).
@@ -156,8 +163,8 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         rr = rr < 0 ? -rr : rr;
         rr = rr >= H ? 2 * H - 2 - rr : rr;
         if (H <= R + 1) rr = r101(yy + 1, H);
-        const int rn = rr * pitch;
-        const double na0 = I1l[rn], na1 = I1c[rn], nb0 = I2l[rn], nb1 = I2c[rn];
+        const int rn = (rr - row_lo) * pitchb;
+        const double na0 = buf_ld(rI1, vxl, rn), na1 = buf_ld(rI1, vxc, rn), nb0 = buf_ld(rI2, vxl, rn), nb1 = buf_ld(rI2, vxc, rn);
         const int y = yy - R;                                   // output row of this iteration
         const bool out_row = i >= 2 * R;
         // the NEXT coarse row of the "+= pyrUp" term is turned into the new carried slot in the epilogue of
@@ -167,10 +174,10 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         // ends up waiting for the image loads issued just above on every odd row.
         [[maybe_unused]] double uA = 0, uB = 0, uC = 0, vA = 0, vB = 0, vC = 0;
         if (HAS_UP) {
-            const int sr = up_srow(((y + 1) >> 1) + 1);
-            const double *ru = CU + sr * cpu, *rv = CV + sr * cpv;
-            uA = ru[us.jm]; uB = ru[us.jc]; uC = ru[us.jp];
-            vA = rv[us.jm]; vB = rv[us.jc]; vC = rv[us.jp];
+            const int sr = max(up_srow(((y + 1) >> 1) + 1) - crow_lo, 0);   // apron rows: clamped, value unused
+            const int su = sr * cpub, sv = sr * cpvb;
+            uA = buf_ld(rCU, us.jm, su); uB = buf_ld(rCU, us.jc, su); uC = buf_ld(rCU, us.jp, su);
+            vA = buf_ld(rCV, us.jm, sv); vB = buf_ld(rCV, us.jc, sv); vC = buf_ld(rCV, us.jp, sv);
         }
         double p[5];
         {
@@ -256,8 +263,8 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
                     v += (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);
                 }
             }
-            a.u.at(pair)[y * (int)a.u.pitch + x] = u;
-            a.v.at(pair)[y * (int)a.v.pitch + x] = v;
+            buf_st(rU, vxo, (y - y0) * upb, u);
+            buf_st(rV, vxo, (y - y0) * vpb, v);
         }
 #ifdef LK3_STAMPS
         LK3_STAMP(t6);

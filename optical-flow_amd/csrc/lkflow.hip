@@ -303,6 +303,7 @@ int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int p
 #define LK_PD_TH 16
 #endif
     a.th = LK_PD_TH;
+    { static const int e = getenv("LKFLOW_PD_TH") ? atoi(getenv("LKFLOW_PD_TH")) : 0; if (e > 0) a.th = e; }
     a.gx = (a.Wd + 4 * lk::PD_WCOLS - 1) / (4 * lk::PD_WCOLS); a.gy = (a.Hd + a.th - 1) / a.th;
     a.vec_src = vec16(src.base, src.plane, src.pitch);
     const long long n = (long long)a.gx * a.gy * planes;
@@ -322,6 +323,7 @@ int launch_warp(lkflow_ctx *ctx, CPlanes i1, CPlanes i2, int H, int W, CPlanes c
 #define LK_WARP_TH 16
 #endif
     a.th = LK_WARP_TH;                           // even; two rows per iteration
+    { static const int e = getenv("LKFLOW_WARP_TH") ? atoi(getenv("LKFLOW_WARP_TH")) : 0; if (e > 0) a.th = e & ~1; }
     a.gx = (W + 255) / 256; a.gy = (H + a.th - 1) / a.th;
     const long long n = (long long)a.gx * a.gy * pairs;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
