@@ -148,6 +148,30 @@ int lkflow_u8_to_f64_dev(lkflow_ctx *ctx, const unsigned char *src, double *dst,
                          void *stream);
 
 /*
+ * Frame pre-processing of the video loop (ParallelVideoPyr.cpp:786-787): GaussianBlur(frame, frame,
+ * Size(ksize,ksize), sigma, sigma) on the 8UC3 (BGR, interleaved) frame followed by
+ * cvtColor(.., CV_BGR2GRAY); OpenCV 2.4's 8-bit fixed-point arithmetic (x86 SSE2 build: column pass rounds
+ * half to even).  The reference calls it with ksize 9, sigma 1.5.  ksize odd, <= 15; sigma > 0.
+ * bgr: n_frames frames of rows x cols x 3 bytes (row step src_step_bytes); gray: rows x cols bytes each.
+ * (The resize to 1080 x 1080 that precedes it, :778, is not part of this library: pass frames of the
+ * size the flow should run at.)
+ */
+int lkflow_blur_gray_bgr8_dev(lkflow_ctx *ctx, const unsigned char *bgr, size_t src_plane_stride_bytes,
+                              int n_frames, int rows, int cols, size_t src_step_bytes, int ksize, double sigma,
+                              unsigned char *gray, size_t dst_plane_stride_bytes, size_t dst_step_bytes,
+                              void *stream);
+
+/*
+ * diff = cur - rate * prev on 8UC1 frames (ParallelVideoPyr.cpp:800, rate = LEARNING_RATE 0.3), i.e.
+ * cv::addWeighted(cur, 1, prev, -rate, 0): float arithmetic, round half to even, saturated to 0..255.
+ * Plane p reads cur + p*stride and prev + p*stride (a video: prev = gray, cur = gray + frame stride).
+ */
+int lkflow_frame_diff_u8_dev(lkflow_ctx *ctx, const unsigned char *cur, const unsigned char *prev,
+                             size_t src_plane_stride_bytes, int n_planes, int rows, int cols,
+                             size_t src_step_bytes, double rate, unsigned char *diff,
+                             size_t dst_plane_stride_bytes, size_t dst_step_bytes, void *stream);
+
+/*
  * The video loop's last pre-processing step, i.e. what PRODUCES the hot call's CV_64F inputs from the
  * 8-bit frame difference (ParallelVideoPyr.cpp:803-813): threshold(diff, thresh, 255, THRESH_TOZERO);
  * Sobel x + Sobel y (CV_64F, 3x3, reflect-101); dilate x2; erode x2 (3x3 rectangle, outside ignored).

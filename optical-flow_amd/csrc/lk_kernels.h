@@ -6,6 +6,8 @@
 //   warp_kernel           a9+a10+a11  pyrUp(flow) -> float map -> fixed-point bilinear remap (1x4 strips)
 //   lk_march3_kernel<WIN> a3..a8  derivatives, products, win x win sums, 2x2 solve, += pyrUp(flow)  (lk_march3.h)
 //   lk_naive_kernel       a3..a8  per-pixel restatement (cross-check only)
+//   blur_gray_kernel      f2   GaussianBlur(k x k, sigma) on 8UC3 + BGR2GRAY (OpenCV 2.4 fixed point)
+//   frame_diff_kernel     f2   cur - rate*prev on 8UC1 (addWeighted float arithmetic)
 //   edge_map_kernel       f2   threshold + Sobel x+y + dilate x2 + erode x2 (uint8 diff -> CV_64F input)
 //   u8_to_f64_kernel      a15  convertTo(CV_64F, 1/255)
 //   centroid_kernel       f1   |flow| threshold + centroid sums
@@ -390,6 +392,97 @@ __global__ __launch_bounds__(256) void edge_map_kernel(EdgeArgs a)
             dst[(long long)yy * a.dst.pitch + xx] = (double)m;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// f2: GaussianBlur(Size(k,k), sigma) on the 8UC3 frame + cvtColor(BGR2GRAY)  (ParallelVideoPyr.cpp:786-787)
+// OpenCV 2.4 fixed-point path: integer kernel q (sum 256), row pass 8U -> 32S, column pass / 65536
+// rounded half to even (the SSE2 column filter of the reference's x86-64 build), reflect-101;
+// gray = (B*1868 + G*9617 + R*4899 + 8192) >> 14.  One block = 64 x 16 output pixels; the input tile
+// (+ apron) and the row-pass result live in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int BG_TW = 64, BG_TH = 16, BG_MAXR = 7;
+struct BlurGrayArgs {
+    const unsigned char *src;   // n_frames x rows x (cols*3) interleaved BGR
+    long long src_plane, src_pitch;
+    unsigned char *dst;         // n_frames x rows x cols
+    long long dst_plane, dst_pitch;
+    int H, W, r;                // r = ksize / 2
+    int q[2 * BG_MAXR + 1];     // integer kernel, q[j + r] for tap j in [-r, r]
+    int gx, gy;
+};
+
+__global__ __launch_bounds__(256) void blur_gray_kernel(BlurGrayArgs a)
+{
+    constexpr int IW = BG_TW + 2 * BG_MAXR, IH = BG_TH + 2 * BG_MAXR;
+    __shared__ unsigned char s_in[IH][IW * 3 + 2];
+    __shared__ int s_row[IH][BG_TW * 3];
+
+    const unsigned n = gridDim.x;
+    unsigned tile = xcd_tile_id(blockIdx.x, n);
+    const int bx = tile % a.gx; tile /= a.gx;
+    const int by = tile % a.gy;
+    const int frame = tile / a.gy;
+    const int H = a.H, W = a.W, r = a.r, t = threadIdx.x;
+    const int x0 = bx * BG_TW, y0 = by * BG_TH;
+    const int iw = BG_TW + 2 * r, ih = BG_TH + 2 * r;
+    const unsigned char *src = a.src + (long long)frame * a.src_plane;
+
+    for (int i = t; i < ih * iw; i += 256) {                 // input tile, reflect-101
+        const int rr = i / iw, c = i - rr * iw;
+        const unsigned char *px = src + (long long)r101(y0 - r + rr, H) * a.src_pitch + (long long)r101(x0 - r + c, W) * 3;
+        s_in[rr][c * 3 + 0] = px[0]; s_in[rr][c * 3 + 1] = px[1]; s_in[rr][c * 3 + 2] = px[2];
+    }
+    __syncthreads();
+    for (int i = t; i < ih * BG_TW * 3; i += 256) {          // row pass (every channel of every tile row)
+        const int rr = i / (BG_TW * 3), xc = i - rr * (BG_TW * 3);
+        int sum = 0;
+        for (int j = 0; j <= 2 * r; ++j) sum += a.q[j] * (int)s_in[rr][xc + 3 * j];
+        s_row[rr][xc] = sum;
+    }
+    __syncthreads();
+    for (int i = t; i < BG_TH * BG_TW; i += 256) {           // column pass + BGR2GRAY
+        const int yy = i / BG_TW, xx = i - yy * BG_TW;
+        const int y = y0 + yy, x = x0 + xx;
+        if (y >= H || x >= W) continue;
+        int px[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int sum = 0;                                     // <= 255 * 65536: fits
+            for (int j = 0; j <= 2 * r; ++j) sum += a.q[j] * s_row[yy + j][xx * 3 + c];
+            int q = sum >> 16;
+            const int rem = sum & 0xFFFF;
+            if (rem > 0x8000 || (rem == 0x8000 && (q & 1))) ++q;
+            px[c] = min(max(q, 0), 255);
+        }
+        a.dst[(long long)frame * a.dst_plane + (long long)y * a.dst_pitch + x] =
+            (unsigned char)((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// f2: diff = cur - rate * prev on 8UC1 frames (ParallelVideoPyr.cpp:800) = cv::addWeighted(cur, 1,
+// prev, -rate, 0): FLOAT arithmetic, every product and sum rounded, round-half-even, saturate.
+// ------------------------------------------------------------------------------------------------
+struct FrameDiffArgs {
+    const unsigned char *cur, *prev;
+    long long src_plane, src_pitch;
+    unsigned char *dst;
+    long long dst_plane, dst_pitch;
+    int H, W;
+    float beta;                 // (float)(-rate)
+};
+
+__global__ __launch_bounds__(256) void frame_diff_kernel(FrameDiffArgs a)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, p = blockIdx.z;
+    if (x >= a.W) return;
+    const long long si = (long long)p * a.src_plane + (long long)y * a.src_pitch + x;
+    const float ta = __fmul_rn((float)a.cur[si], 1.0f);
+    const float tb = __fmul_rn((float)a.prev[si], a.beta);
+    const float tt = __fadd_rn(__fadd_rn(ta, tb), 0.0f);
+    const int v = __float2int_rn(tt);
+    a.dst[(long long)p * a.dst_plane + (long long)y * a.dst_pitch + x] = (unsigned char)min(max(v, 0), 255);
 }
 
 // ------------------------------------------------------------------------------------------------

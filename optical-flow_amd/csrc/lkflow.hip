@@ -7,6 +7,7 @@
 // call into a HIP graph after lkflow_ctx_reserve().
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -719,6 +720,63 @@ int lkflow_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *src, size_t src
     const long long n = (long long)a.gx * a.gy * n_planes;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
     hipLaunchKernelGGL(lk::edge_map_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
+int lkflow_blur_gray_bgr8_dev(lkflow_ctx *ctx, const unsigned char *bgr, size_t src_ps, int n_frames, int rows,
+                              int cols, size_t src_step_bytes, int ksize, double sigma, unsigned char *gray,
+                              size_t dst_ps, size_t dst_step_bytes, void *stream)
+{
+    if (!ctx || !bgr || !gray || rows < 1 || cols < 1 || n_frames < 1) return LKFLOW_E_ARG;
+    if (src_step_bytes < (size_t)cols * 3 || dst_step_bytes < (size_t)cols) return LKFLOW_E_ARG;
+    if (ksize < 1 || ksize > 2 * lk::BG_MAXR + 1 || !(ksize & 1)) return LKFLOW_E_WIN;
+    if (!(sigma > 0.0)) return LKFLOW_E_ARG;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    lk::BlurGrayArgs a{};
+    // cv::getGaussianKernel(ksize, sigma, CV_32F) -> convertTo(CV_32S, 256) (OpenCV 2.4 smooth.cpp / filter.cpp)
+    {
+        float cf[2 * lk::BG_MAXR + 1];
+        const double scale2x = -0.5 / (sigma * sigma);
+        double sum = 0.0;
+        for (int i = 0; i < ksize; ++i) {
+            const double x = i - (ksize - 1) * 0.5;
+            cf[i] = (float)std::exp(scale2x * x * x);
+            sum += cf[i];
+        }
+        sum = 1.0 / sum;
+        for (int i = 0; i < ksize; ++i) {
+            cf[i] = (float)(cf[i] * sum);
+            a.q[i] = (int)std::lrint((double)(cf[i] * 256.0f));
+        }
+    }
+    a.src = bgr; a.src_plane = (long long)src_ps; a.src_pitch = (long long)src_step_bytes;
+    a.dst = gray; a.dst_plane = (long long)dst_ps; a.dst_pitch = (long long)dst_step_bytes;
+    a.H = rows; a.W = cols; a.r = ksize / 2;
+    a.gx = (cols + lk::BG_TW - 1) / lk::BG_TW; a.gy = (rows + lk::BG_TH - 1) / lk::BG_TH;
+    const long long n = (long long)a.gx * a.gy * n_frames;
+    if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
+    hipLaunchKernelGGL(lk::blur_gray_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
+int lkflow_frame_diff_u8_dev(lkflow_ctx *ctx, const unsigned char *cur, const unsigned char *prev, size_t src_ps,
+                             int n_planes, int rows, int cols, size_t src_step_bytes, double rate,
+                             unsigned char *diff, size_t dst_ps, size_t dst_step_bytes, void *stream)
+{
+    if (!ctx || !cur || !prev || !diff || rows < 1 || cols < 1 || n_planes < 1 || n_planes > 65535 || rows > 65535)
+        return LKFLOW_E_ARG;
+    if (src_step_bytes < (size_t)cols || dst_step_bytes < (size_t)cols) return LKFLOW_E_ARG;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    lk::FrameDiffArgs a{};
+    a.cur = cur; a.prev = prev; a.src_plane = (long long)src_ps; a.src_pitch = (long long)src_step_bytes;
+    a.dst = diff; a.dst_plane = (long long)dst_ps; a.dst_pitch = (long long)dst_step_bytes;
+    a.H = rows; a.W = cols; a.beta = (float)(-rate);
+    hipLaunchKernelGGL(lk::frame_diff_kernel, dim3((cols + 255) / 256, rows, n_planes), dim3(256), 0,
+                       (hipStream_t)stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }

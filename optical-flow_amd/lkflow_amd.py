@@ -65,6 +65,8 @@ SIGNATURES = {
     "lkflow_warp_f64_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _vp, _vp, _sz, _sz, _vp, _vp,
                                  _sz, _sz, _vp]),
     "lkflow_u8_to_f64_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "lkflow_blur_gray_bgr8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _i, _d, _vp, _sz, _sz, _vp]),
+    "lkflow_frame_diff_u8_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _vp, _sz, _sz, _vp]),
     "lkflow_edge_map_u8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _i, _vp, _sz, _sz, _vp]),
     "lkflow_flow_centroid_f64_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _vp, _vp]),
 }
@@ -329,6 +331,42 @@ class Context:
         self._chk(lib().lkflow_u8_to_f64_dev(self._h, src.data_ptr(), dst.data_ptr(), src.numel(),
                                              _stream_ptr(stream)))
         return dst
+
+    def blur_gray(self, bgr_u8, ksize=9, sigma=1.5, stream=None):
+        """[N,H,W,3] uint8 BGR frames -> [N,H,W] uint8: GaussianBlur(ksize x ksize, sigma) on the colour frame,
+        then BGR2GRAY (ParallelVideoPyr.cpp:786-787; OpenCV 2.4 8-bit fixed-point arithmetic)."""
+        torch = _torch()
+        assert bgr_u8.is_cuda and bgr_u8.dtype == torch.uint8
+        if bgr_u8.dim() == 3:
+            bgr_u8 = bgr_u8.unsqueeze(0)
+        assert bgr_u8.shape[-1] == 3 and bgr_u8.stride(-1) == 1 and bgr_u8.stride(2) == 3
+        N, H, W, _ = bgr_u8.shape
+        out = torch.empty((N, H, W), dtype=torch.uint8, device=bgr_u8.device)
+        self._chk(lib().lkflow_blur_gray_bgr8_dev(self._h, bgr_u8.data_ptr(), bgr_u8.stride(0), N, H, W,
+                                                  bgr_u8.stride(1), int(ksize), float(sigma), out.data_ptr(),
+                                                  out.stride(0), out.stride(1), _stream_ptr(stream)))
+        return out
+
+    def frame_diff(self, gray_u8, rate=0.3, stream=None):
+        """[F,H,W] uint8 gray frames -> [F-1,H,W] uint8: frame[k+1] - rate*frame[k], saturated
+        (ParallelVideoPyr.cpp:800, cv::addWeighted float arithmetic)."""
+        torch = _torch()
+        assert gray_u8.is_cuda and gray_u8.dtype == torch.uint8 and gray_u8.dim() == 3 and gray_u8.stride(-1) == 1
+        F, H, W = gray_u8.shape
+        assert F >= 2
+        out = torch.empty((F - 1, H, W), dtype=torch.uint8, device=gray_u8.device)
+        self._chk(lib().lkflow_frame_diff_u8_dev(self._h, gray_u8[1:].data_ptr(), gray_u8.data_ptr(),
+                                                 gray_u8.stride(0), F - 1, H, W, gray_u8.stride(1), float(rate),
+                                                 out.data_ptr(), out.stride(0), out.stride(1),
+                                                 _stream_ptr(stream)))
+        return out
+
+    def preprocess_bgr(self, bgr_u8, ksize=9, sigma=1.5, rate=0.3, thresh=10, stream=None):
+        """The video loop's whole per-frame chain after the resize (ParallelVideoPyr.cpp:786-813):
+        [F,H,W,3] uint8 BGR frames -> [F-1,H,W] float64 edge images, the inputs of the hot call
+        (consecutive edge images form the F-2 frame pairs)."""
+        gray = self.blur_gray(bgr_u8, ksize, sigma, stream)
+        return self.edge_map(self.frame_diff(gray, rate, stream), thresh, stream)
 
     def edge_map(self, diff_u8, thresh=10, stream=None):
         """[N,H,W] uint8 frame differences -> [N,H,W] float64 edge images (ParallelVideoPyr.cpp:803-813:

@@ -441,3 +441,86 @@ void lko_edge_map_u8(const unsigned char *diff, int rows, int cols, int thresh, 
     morph3x3(t, rows, cols, 0, out);
     free(t); free(e);
 }
+
+/*
+ * ParallelVideoPyr.cpp:786-787 -- GaussianBlur(frame, frame, Size(k,k), sigma, sigma) on the 8UC3 frame, then
+ * cvtColor(.., CV_BGR2GRAY).  PARITY UNPINNED: the reference holds no fixture for its pre-processing chain
+ * and OpenCV is absent, so this restates OpenCV 2.4's published 8-bit algorithms:
+ *   getGaussianKernel(n, sigma, CV_32F) (smooth.cpp): cf[i] = (float)exp(-0.5/sigma^2 * x^2), sum over the
+ *     floats, cf[i] = (float)(cf[i] * (1/sum));
+ *   createSeparableLinearFilter (filter.cpp), 8U -> 8U with a smooth symmetric kernel: fixed point, bits = 8:
+ *     integer kernel = cvRound(cf[i] * 256); row pass 8U -> 32S; column pass (sum of 16-bit-scaled products)
+ *     rounded to 8U.  The x86 SSE2 column filter (SymmColumnVec_32s8u, what the reference's x86-64 binary
+ *     runs for every column of a 1080-wide BGR row) evaluates the exact sum in float and converts with
+ *     round-half-to-EVEN; the scalar tail (FixedPtCastEx) would round half up.  The two differ only on exact
+ *     ties; this restatement follows the SSE2 build.  BORDER_DEFAULT = reflect-101.
+ *   cvtColor BGR2GRAY 8U (color.cpp RGB2Gray<uchar>): (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+ * For (9, 1.5) the integer kernel is [2 9 28 55 68 55 28 9 2] (sum 256).
+ */
+void lko_gaussian_kernel_q8(int n, double sigma, int *k)
+{
+    float cf[64];
+    double scale2x = -0.5 / (sigma * sigma), sum = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double x = i - (n - 1) * 0.5;
+        cf[i] = (float)exp(scale2x * x * x);
+        sum += cf[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < n; ++i) {
+        cf[i] = (float)(cf[i] * sum);
+        k[i] = (int)lrint((double)(cf[i] * 256.0f));     /* convertTo(CV_32S, 1 << 8): cvRound of the float product */
+    }
+}
+
+void lko_blur_gray_bgr8(const unsigned char *bgr, int rows, int cols, int ksize, double sigma,
+                        unsigned char *gray)
+{
+    int k[64];
+    const int r = ksize / 2;
+    lko_gaussian_kernel_q8(ksize, sigma, k);
+    int *row = (int *)malloc((size_t)rows * cols * 3 * sizeof(int));
+    for (int y = 0; y < rows; ++y)                           /* row pass: 8U -> 32S */
+        for (int x = 0; x < cols; ++x)
+            for (int c = 0; c < 3; ++c) {
+                int s = 0;
+                for (int j = -r; j <= r; ++j)
+                    s += k[j + r] * bgr[((size_t)y * cols + r101(x + j, cols)) * 3 + c];
+                row[((size_t)y * cols + x) * 3 + c] = s;
+            }
+    for (int y = 0; y < rows; ++y)                           /* column pass + BGR2GRAY */
+        for (int x = 0; x < cols; ++x) {
+            int px[3];
+            for (int c = 0; c < 3; ++c) {
+                long long s = 0;
+                for (int j = -r; j <= r; ++j)
+                    s += (long long)k[j + r] * row[((size_t)r101(y + j, rows) * cols + x) * 3 + c];
+                long long q = s >> 16, rem = s & 0xFFFF;     /* s / 65536 rounded half to even */
+                if (rem > 0x8000 || (rem == 0x8000 && (q & 1))) ++q;
+                px[c] = q < 0 ? 0 : (q > 255 ? 255 : (int)q);
+            }
+            gray[(size_t)y * cols + x] = (unsigned char)((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14);
+        }
+    free(row);
+}
+
+/*
+ * ParallelVideoPyr.cpp:800 -- Mat diff = current_frame - LEARNING_RATE * prevFrame on 8UC1 frames.
+ * PARITY UNPINNED (no fixture).  OpenCV 2.4: the MatExpr lowers to addWeighted(cur, 1, prev, -rate, 0)
+ * (matop.cpp MatOp_AddEx::assign), whose 8-bit kernel (arithm.cpp addWeighted8u, SSE2 and scalar alike)
+ * computes in FLOAT: t = (float)cur*alpha + (float)prev*beta + gamma with alpha, beta, gamma cast to float,
+ * every product and sum rounded to float, then saturate_cast<uchar>(cvRound(t)) (round half to even).
+ */
+void lko_frame_diff_u8(const unsigned char *cur, const unsigned char *prev, long n, double rate,
+                       unsigned char *diff)
+{
+    const float alpha = 1.0f, beta = (float)(-rate), gamma = 0.0f;
+    for (long i = 0; i < n; ++i) {
+        volatile float a = (float)cur[i] * alpha;            /* volatile: every step rounded to float */
+        volatile float b = (float)prev[i] * beta;
+        volatile float t = a + b;
+        t = t + gamma;
+        long v = lrintf(t);
+        diff[i] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}

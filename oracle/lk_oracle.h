@@ -64,6 +64,16 @@ void lko_flow_centroid(const double *u, const double *v, int rows, int cols, dou
  * dilate x2; erode x2 (3x3 rect, outside pixels ignored).  All values are exact integers. */
 void lko_edge_map_u8(const unsigned char *diff, int rows, int cols, int thresh, double *out);
 
+/* ParallelVideoPyr.cpp:786-787 GaussianBlur(Size(k,k), sigma) on 8UC3 + cvtColor(BGR2GRAY) -> 8UC1.
+ * PARITY UNPINNED (no reference fixture covers the pre-processing chain; OpenCV 2.4 fixed-point restated). */
+void lko_gaussian_kernel_q8(int n, double sigma, int *k);
+void lko_blur_gray_bgr8(const unsigned char *bgr, int rows, int cols, int ksize, double sigma,
+                        unsigned char *gray);
+
+/* ParallelVideoPyr.cpp:800 diff = cur - rate*prev on 8UC1 (addWeighted8u float arithmetic). PARITY UNPINNED. */
+void lko_frame_diff_u8(const unsigned char *cur, const unsigned char *prev, long n, double rate,
+                       unsigned char *diff);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,13 @@ def lib():
         L.lko_flow_centroid.restype = None
         L.lko_edge_map_u8.argtypes = [ctypes.POINTER(ctypes.c_ubyte), ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp]
         L.lko_edge_map_u8.restype = None
+        _bp = ctypes.POINTER(ctypes.c_ubyte)
+        L.lko_gaussian_kernel_q8.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int)]
+        L.lko_gaussian_kernel_q8.restype = None
+        L.lko_blur_gray_bgr8.argtypes = [_bp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, _bp]
+        L.lko_blur_gray_bgr8.restype = None
+        L.lko_frame_diff_u8.argtypes = [_bp, _bp, ctypes.c_long, ctypes.c_double, _bp]
+        L.lko_frame_diff_u8.restype = None
         _LIB = L
     return _LIB
 
@@ -165,6 +172,32 @@ def edge_map_u8(diff, thresh=10):
     out = np.empty(diff.shape, dtype=np.float64)
     lib().lko_edge_map_u8(diff.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), diff.shape[0], diff.shape[1],
                           int(thresh), _p(out))
+    return out
+
+
+def gaussian_kernel_q8(ksize=9, sigma=1.5):
+    k = (ctypes.c_int * ksize)()
+    lib().lko_gaussian_kernel_q8(ksize, float(sigma), k)
+    return np.array(list(k), dtype=np.int64)
+
+
+def blur_gray_bgr8(bgr, ksize=9, sigma=1.5):
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    assert bgr.ndim == 3 and bgr.shape[2] == 3
+    out = np.empty(bgr.shape[:2], dtype=np.uint8)
+    _bp = ctypes.POINTER(ctypes.c_ubyte)
+    lib().lko_blur_gray_bgr8(bgr.ctypes.data_as(_bp), bgr.shape[0], bgr.shape[1], ksize, float(sigma),
+                             out.ctypes.data_as(_bp))
+    return out
+
+
+def frame_diff_u8(cur, prev, rate=0.3):
+    cur, prev = np.ascontiguousarray(cur, dtype=np.uint8), np.ascontiguousarray(prev, dtype=np.uint8)
+    assert cur.shape == prev.shape
+    out = np.empty(cur.shape, dtype=np.uint8)
+    _bp = ctypes.POINTER(ctypes.c_ubyte)
+    lib().lko_frame_diff_u8(cur.ctypes.data_as(_bp), prev.ctypes.data_as(_bp), cur.size, float(rate),
+                            out.ctypes.data_as(_bp))
     return out
 
 

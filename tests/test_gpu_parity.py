@@ -348,3 +348,57 @@ def test_edge_map_bit_exact(gpu_ctx, oracle, torch, table_u8, shape):
     got = host(gpu_ctx.edge_map(dev(torch, d), 10))
     for k in range(2):
         assert np.array_equal(got[k], oracle.edge_map_u8(d[k], 10))
+
+
+# ---------------------------------------------------------------- f2 pre-processing (oracle: parity unpinned)
+@pytest.mark.parametrize("shape", [(448, 640), (1, 1), (3, 4), (9, 2), (37, 129), (1080, 1080)])
+def test_blur_gray_bit_exact(gpu_ctx, oracle, torch, shape):
+    """ParallelVideoPyr.cpp:786-787 GaussianBlur(9x9, 1.5) on 8UC3 + BGR2GRAY: integer arithmetic, bit-exact."""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    f = rng.integers(0, 256, (2,) + shape + (3,)).astype(np.uint8)
+    f[1, : shape[0] // 2] = (255, 0, 128)
+    got = host(gpu_ctx.blur_gray(dev(torch, f), 9, 1.5))
+    for k in range(2):
+        assert np.array_equal(got[k], oracle.blur_gray_bgr8(f[k], 9, 1.5))
+
+
+@pytest.mark.parametrize("ksize,sigma", [(3, 0.8), (5, 1.0), (7, 2.0), (15, 3.0)])
+def test_blur_gray_other_kernels(gpu_ctx, oracle, torch, ksize, sigma):
+    rng = np.random.default_rng(ksize)
+    f = rng.integers(0, 256, (1, 50, 70, 3)).astype(np.uint8)
+    assert np.array_equal(host(gpu_ctx.blur_gray(dev(torch, f), ksize, sigma))[0], oracle.blur_gray_bgr8(f[0], ksize, sigma))
+
+
+def test_blur_gray_argument_errors(gpu_ctx, lkflow, torch):
+    f = torch.zeros((1, 8, 8, 3), dtype=torch.uint8, device="cuda")
+    for ksize, sigma in [(4, 1.0), (17, 1.0), (9, 0.0), (9, -1.0)]:
+        with pytest.raises(lkflow.LKFlowError):
+            gpu_ctx.blur_gray(f, ksize, sigma)
+
+
+def test_frame_diff_bit_exact(gpu_ctx, oracle, torch):
+    """ParallelVideoPyr.cpp:800 cur - 0.3*prev (addWeighted float arithmetic): every (cur, prev) byte pair."""
+    a, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
+    frames = np.stack([b, a, b])                                   # diffs: a - .3 b, b - .3 a
+    got = host(gpu_ctx.frame_diff(dev(torch, frames), 0.3))
+    assert np.array_equal(got[0], oracle.frame_diff_u8(a, b, 0.3))
+    assert np.array_equal(got[1], oracle.frame_diff_u8(b, a, 0.3))
+
+
+def test_preprocess_chain_feeds_the_hot_call(gpu_ctx, oracle, torch):
+    """BGR frames -> blur/gray -> frame difference -> edge map (ParallelVideoPyr.cpp:786-813) -> flow: the whole
+    device-resident video path against the oracle chained the same way."""
+    import synth
+    h, w, F = 64, 96, 4
+    base = synth.video(F, h, w, seed=5)                             # [F,h,w] float64 in [0,1]
+    bgr = np.stack([np.clip(base * s, 0, 1) for s in (255, 200, 150)], axis=-1).astype(np.uint8)
+    edges = host(gpu_ctx.preprocess_bgr(dev(torch, bgr)))
+    gray = [oracle.blur_gray_bgr8(bgr[k]) for k in range(F)]
+    want = [oracle.edge_map_u8(oracle.frame_diff_u8(gray[k + 1], gray[k], 0.3), 10) for k in range(F - 1)]
+    for k in range(F - 1):
+        assert np.array_equal(edges[k], want[k])
+    U, V = gpu_ctx.compute_video(dev(torch, np.stack(want)), levels=3, win=5)
+    for p in range(F - 2):
+        uo, vo = oracle.coarse_to_fine(want[p], want[p + 1], 3, 5)
+        scale = max(1.0, np.abs(uo).max(), np.abs(vo).max())
+        assert np.abs(host(U[p]) - uo).max() <= TOL * scale and np.abs(host(V[p]) - vo).max() <= TOL * scale

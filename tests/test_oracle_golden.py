@@ -152,3 +152,57 @@ def test_edge_map_oracle_matches_direct_5x5_formulation(oracle):
         return np.array([[f(a[max(0, y - 2):y + 3, max(0, x - 2):x + 3]) for x in range(W)] for y in range(H)])
     assert np.array_equal(got, mm(mm(e, np.max), np.min))
     assert not oracle.edge_map_u8(np.full((9, 9), 7, np.uint8), 10).any()      # below threshold -> flat -> 0
+
+
+# ------------------------------------------------------------------ f2 pre-processing (PARITY UNPINNED)
+# The reference holds no fixture for ParallelVideoPyr.cpp:786-800 and OpenCV is absent: these tests pin the
+# C oracle to an independent NumPy/SciPy restatement of the OpenCV 2.4 fixed-point algorithms it documents.
+def test_gaussian_kernel_q8(oracle):
+    k = oracle.gaussian_kernel_q8(9, 1.5)
+    assert k.tolist() == [2, 9, 28, 55, 68, 55, 28, 9, 2] and k.sum() == 256
+    k5 = oracle.gaussian_kernel_q8(5, 1.0)
+    assert k5.tolist() == k5[::-1].tolist() and abs(int(k5.sum()) - 256) <= 2
+
+
+@pytest.mark.parametrize("shape", [(40, 50), (3, 4), (1, 1), (9, 2)])
+def test_blur_gray_oracle_matches_numpy(oracle, shape):
+    from scipy.ndimage import correlate1d
+    rng = np.random.default_rng(shape[0] * 13 + shape[1])
+    img = rng.integers(0, 256, shape + (3,)).astype(np.uint8)
+    k = oracle.gaussian_kernel_q8(9, 1.5)
+
+    def r101(i, n):
+        if n == 1:
+            return 0
+        while i < 0 or i >= n:
+            i = -i if i < 0 else 2 * n - 2 - i
+        return i
+
+    def corr(a, axis):      # reflect-101 correlation with multi-reflection for images shorter than the radius
+        n = a.shape[axis]
+        idx = np.array([[r101(i + j, n) for j in range(-4, 5)] for i in range(n)])
+        g = np.take(a, idx, axis=axis)                 # axis -> (n, 9)
+        return np.tensordot(g, k, axes=([axis + 1], [0]))
+    c = corr(corr(img.astype(np.int64), 1), 0)
+    if min(shape) > 4:                                 # scipy's 'mirror' == reflect-101 when one reflection suffices
+        assert np.array_equal(c, correlate1d(correlate1d(img.astype(np.int64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror"))
+    q, rem = c >> 16, c & 0xFFFF
+    q = np.clip(q + ((rem > 0x8000) | ((rem == 0x8000) & ((q & 1) == 1))), 0, 255)
+    gray = (q[..., 0] * 1868 + q[..., 1] * 9617 + q[..., 2] * 4899 + 8192) >> 14
+    assert np.array_equal(oracle.blur_gray_bgr8(img), gray.astype(np.uint8))
+
+
+def test_blur_gray_constant_frame(oracle):
+    img = np.empty((12, 17, 3), np.uint8)
+    img[..., 0], img[..., 1], img[..., 2] = 10, 200, 90           # B, G, R
+    want = (10 * 1868 + 200 * 9617 + 90 * 4899 + 8192) >> 14
+    assert (oracle.blur_gray_bgr8(img) == want).all()            # kernel sums to 256: a flat frame is unchanged
+
+
+def test_frame_diff_oracle_matches_float32_numpy(oracle):
+    a, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))   # every (cur, prev) pair
+    t = a.astype(np.float32) * np.float32(1) + b.astype(np.float32) * np.float32(-0.3)
+    want = np.clip(np.rint(t), 0, 255).astype(np.uint8)
+    got = oracle.frame_diff_u8(a, b, 0.3)
+    assert np.array_equal(got, want)
+    assert got[255, 0] == 0 and got[0, 255] == 255               # saturates at 0; cur alone passes through
