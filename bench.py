@@ -105,6 +105,26 @@ def pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, device, world, chun
             "unit": "Mpixels/s", "note": "rank 0 only, extra measurement after the timed region"}
 
 
+def preprocess_rate(ctx, torch, device, frames=33, side=1080, steps=20):
+    """Extra, NOT the headline: the video loop's per-frame chain that produces the hot call's inputs
+    (ParallelVideoPyr.cpp:786-813) at the reference's 1080 x 1080 working size: blur 9x9 + BGR2GRAY,
+    then cur - 0.3*prev fused with threshold + Sobel x+y + dilate x2 + erode x2.  Algorithmic bytes per frame
+    pixel: 3+1 (blur/gray) + 2+8 (difference + edge map) = 14 B."""
+    g = torch.Generator(device="cpu").manual_seed(7)
+    bgr = torch.randint(0, 256, (frames, side, side, 3), dtype=torch.uint8, generator=g).to(f"cuda:{device}")
+    for _ in range(3):
+        ctx.preprocess_bgr(bgr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.preprocess_bgr(bgr)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"frames": frames, "shape": [side, side, 3], "ms_per_batch": round(dt * 1e3, 4),
+            "frames_per_s": round(frames / dt, 1), "algorithmic_GBps": round(14.0 * frames * side * side / dt / 1e9, 1),
+            "note": "rank 0 only, extra measurement after the timed region; uint8 BGR in -> CV_64F edge images out"}
+
+
 def cpu_baseline(cols, rows, levels, win, budget_s=20.0):
     """Times oracle/lk_cpu_omp.c (the restated ParallelVideoPyr.cpp CPU path) on this host."""
     import synth
@@ -312,6 +332,8 @@ def main():
                                         for (s, l), (ms, n) in sorted(prof.items())}
         if world == 1 and K == 1 and not args.graph and P >= 8 and not args.no_extras:
             out["pipelined"] = pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, local_rank, world)
+        if world == 1 and not args.no_extras:
+            out["preprocess"] = preprocess_rate(ctx, torch, local_rank)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(cols, rows, levels, win)
         print(json.dumps(out), flush=True)

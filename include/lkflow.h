@@ -182,6 +182,15 @@ int lkflow_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *src, size_t src
                            size_t dst_plane_stride_bytes, size_t dst_step_bytes, void *stream);
 
 /*
+ * lkflow_frame_diff_u8_dev + lkflow_edge_map_u8_dev in one pass (ParallelVideoPyr.cpp:800-813): the
+ * difference image never reaches memory.  Same results as the two calls in sequence.
+ */
+int lkflow_diff_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *cur, const unsigned char *prev,
+                                size_t src_plane_stride_bytes, int n_planes, int rows, int cols,
+                                size_t src_step_bytes, double rate, int thresh, double *dst,
+                                size_t dst_plane_stride_bytes, size_t dst_step_bytes, void *stream);
+
+/*
  * Flow consumer of the video loop (ParallelVideoPyr.cpp:845-873), batched and fused:
  * for each pair, out[3*p+0] = number of pixels with sqrt(u*u+v*v) >= thresh,
  * out[3*p+1] = sum of their column indices, out[3*p+2] = sum of their row indices (fp64, exact

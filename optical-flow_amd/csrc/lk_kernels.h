@@ -300,52 +300,83 @@ __global__ __launch_bounds__(256) void lk_naive_kernel(LKArgs a, int win)
 //   thresholded pixels (T+10)^2 -> E = sx+sy (T+8)^2 -> row max -> column max = D (T+4)^2
 //   -> row min -> column min = out T^2.          Block = 256 threads = a 64 x 16 output tile.
 // ------------------------------------------------------------------------------------------------
+// cv::addWeighted(cur, 1, prev, beta, 0) for one 8-bit pixel (ParallelVideoPyr.cpp:800): float arithmetic,
+// every product and sum rounded, round half to even, saturated.
+__device__ __forceinline__ int frame_diff_px(unsigned char cur, unsigned char prev, float beta)
+{
+    const float ta = __fmul_rn((float)cur, 1.0f);
+    const float tb = __fmul_rn((float)prev, beta);
+    const int v = __float2int_rn(__fadd_rn(__fadd_rn(ta, tb), 0.0f));
+    return min(max(v, 0), 255);
+}
+
 struct EdgeArgs {
     const unsigned char *src;   // n_planes x rows x cols, contiguous planes, row pitch = src_pitch bytes
+    const unsigned char *prev;  // optional (same layout): the input becomes src - rate*prev (frame_diff_kernel's rule)
+    float beta;                 // (float)(-rate)
     long long src_plane, src_pitch;
     Planes dst;
     int H, W, thresh;
     int gx, gy;
 };
 
-constexpr int EM_TW = 64, EM_TH = 16;
+// Tile = 54 x 32 outputs: with the 5-pixel apron on each side the widest stage is exactly 64 columns,
+// so every stage runs as "one wave per tile row, lane = column" (no index divisions, conflict-free LDS rows).
+constexpr int EM_TW = 54, EM_TH = 32;
 
 __global__ __launch_bounds__(256) void edge_map_kernel(EdgeArgs a)
 {
-    constexpr int PW = EM_TW + 10, PH = EM_TH + 10;     // thresholded pixels
+    constexpr int PW = EM_TW + 10, PH = EM_TH + 10;     // thresholded pixels   (PW == 64)
     constexpr int EW = EM_TW + 8, EH = EM_TH + 8;       // Sobel sum
     constexpr int DW = EM_TW + 4, DH = EM_TH + 4;       // dilated
-    __shared__ int s_t[PH][PW];
-    __shared__ int s_e[EH][EW];
-    __shared__ int s_h[EH][DW];                         // row max of E; later row min of D ([DH][EM_TW])
-    __shared__ int s_d[DH][DW];
+    static_assert(PW == 64, "stage rows are one wave wide");
+    __shared__ int s_t[PH][64];
+    __shared__ int s_e[EH][64];
+    __shared__ int s_h[EH][64];                         // row max of E; later row min of D
+    __shared__ int s_d[DH][64];
 
     const unsigned n = gridDim.x;
     unsigned tile = xcd_tile_id(blockIdx.x, n);
     const int bx = tile % a.gx; tile /= a.gx;
     const int by = tile % a.gy;
     const int plane = tile / a.gy;
-    const int H = a.H, W = a.W, t = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x0 = bx * EM_TW, y0 = by * EM_TH;
     const unsigned char *src = a.src + (long long)plane * a.src_plane;
 
-    // thresholded pixels, reflect-101 (only the Sobel taps of in-image E positions ever read them)
-    for (int i = t; i < PH * PW; i += 256) {
-        const int r = i / PW, c = i - r * PW;
-        const int yy = r101(y0 - 5 + r, H), xx = r101(x0 - 5 + c, W);
-        const int v = src[(long long)yy * a.src_pitch + xx];
-        s_t[r][c] = v > a.thresh ? v : 0;
+    // thresholded pixels, reflect-101 (only the Sobel taps of in-image E positions ever read them); all
+    // byte loads of a thread are issued before the first LDS store (one memory latency per tile)
+    {
+        constexpr int NR = (PH + 3) / 4;
+        int gx = x0 - 5 + lane;
+        gx = gx < 0 ? -gx : gx;
+        gx = gx >= W ? 2 * W - 2 - gx : gx;
+        if (gx < 0 || gx >= W) gx = r101(x0 - 5 + lane, W);   // image narrower than the apron
+        unsigned char v[NR], pv[NR];
+        const unsigned char *prev = a.prev ? a.prev + (long long)plane * a.src_plane : nullptr;   // uniform
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const long long o = (long long)r101(y0 - 5 + min(wave + 4 * k, PH - 1), H) * a.src_pitch + gx;
+            v[k] = src[o];
+            pv[k] = prev ? prev[o] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            int d = v[k];
+            if (prev) d = frame_diff_px(v[k], pv[k], a.beta);
+            if (wave + 4 * k < PH) s_t[wave + 4 * k][lane] = d > a.thresh ? d : 0;
+        }
     }
     __syncthreads();
     // E = Sobel x + Sobel y at (y0-4+r, x0-4+c); positions outside the image = "never wins" for the max
-    for (int i = t; i < EH * EW; i += 256) {
-        const int r = i / EW, c = i - r * EW;
+    for (int r = wave; r < EH; r += 4) {
+        const int c = lane;
         const int yy = y0 - 4 + r, xx = x0 - 4 + c;
         int e = INT_MIN;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            // s_t index of (yy,xx) is [r+1][c+1]; neighbours of border pixels must be the REFLECTED image
-            // pixels, which is what s_t holds only if the neighbour coordinate itself was reflected:
-            // s_t[r+1+dy][c+1+dx] holds pixel r101(yy+dy), r101(xx+dx)  (same mapping) -> correct
+        if (c < EW && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            // s_t index of (yy,xx) is [r+1][c+1]; s_t[r+1+dy][c+1+dx] holds pixel r101(yy+dy), r101(xx+dx),
+            // i.e. the reflected neighbour cv::Sobel reads at the image border
             const int tl = s_t[r][c], tc = s_t[r][c + 1], tr = s_t[r][c + 2];
             const int ml = s_t[r + 1][c], mr = s_t[r + 1][c + 2];
             const int bl = s_t[r + 2][c], bc = s_t[r + 2][c + 1], br = s_t[r + 2][c + 2];
@@ -353,39 +384,45 @@ __global__ __launch_bounds__(256) void edge_map_kernel(EdgeArgs a)
             const int sy = (bl - tl) + 2 * (bc - tc) + (br - tr);
             e = sx + sy;
         }
-        s_e[r][c] = e;
+        if (c < EW) s_e[r][c] = e;
     }
     __syncthreads();
-    for (int i = t; i < EH * DW; i += 256) {            // row max over 5 columns
-        const int r = i / DW, c = i - r * DW;
-        int m = s_e[r][c];
+    for (int r = wave; r < EH; r += 4) {                // row max over 5 columns
+        const int c = lane;
+        if (c < DW) {
+            int m = s_e[r][c];
 #pragma unroll
-        for (int k = 1; k < 5; ++k) m = max(m, s_e[r][c + k]);
-        s_h[r][c] = m;
+            for (int k = 1; k < 5; ++k) m = max(m, s_e[r][c + k]);
+            s_h[r][c] = m;
+        }
     }
     __syncthreads();
-    for (int i = t; i < DH * DW; i += 256) {            // column max -> D at (y0-2+r, x0-2+c)
-        const int r = i / DW, c = i - r * DW;
-        int m = s_h[r][c];
+    for (int r = wave; r < DH; r += 4) {                // column max -> D at (y0-2+r, x0-2+c)
+        const int c = lane;
+        if (c < DW) {
+            int m = s_h[r][c];
 #pragma unroll
-        for (int k = 1; k < 5; ++k) m = max(m, s_h[r + k][c]);
-        const int yy = y0 - 2 + r, xx = x0 - 2 + c;
-        s_d[r][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? m : INT_MAX;   // outside never wins the min
+            for (int k = 1; k < 5; ++k) m = max(m, s_h[r + k][c]);
+            const int yy = y0 - 2 + r, xx = x0 - 2 + c;
+            s_d[r][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? m : INT_MAX;   // outside never wins the min
+        }
     }
     __syncthreads();
-    for (int i = t; i < DH * EM_TW; i += 256) {         // row min over 5 columns (reuses s_h)
-        const int r = i / EM_TW, c = i - r * EM_TW;
-        int m = s_d[r][c];
+    for (int r = wave; r < DH; r += 4) {                // row min over 5 columns (reuses s_h)
+        const int c = lane;
+        if (c < EM_TW) {
+            int m = s_d[r][c];
 #pragma unroll
-        for (int k = 1; k < 5; ++k) m = min(m, s_d[r][c + k]);
-        s_h[r][c] = m;
+            for (int k = 1; k < 5; ++k) m = min(m, s_d[r][c + k]);
+            s_h[r][c] = m;
+        }
     }
     __syncthreads();
     double *dst = a.dst.at(plane);
-    for (int i = t; i < EM_TH * EM_TW; i += 256) {      // column min -> output
-        const int r = i / EM_TW, c = i - r * EM_TW;
+    for (int r = wave; r < EM_TH; r += 4) {             // column min -> output
+        const int c = lane;
         const int yy = y0 + r, xx = x0 + c;
-        if (yy < H && xx < W) {
+        if (c < EM_TW && yy < H && xx < W) {
             int m = s_h[r][c];
 #pragma unroll
             for (int k = 1; k < 5; ++k) m = min(m, s_h[r + k][c]);
@@ -401,62 +438,125 @@ __global__ __launch_bounds__(256) void edge_map_kernel(EdgeArgs a)
 // gray = (B*1868 + G*9617 + R*4899 + 8192) >> 14.  One block = 64 x 16 output pixels; the input tile
 // (+ apron) and the row-pass result live in LDS.
 // ------------------------------------------------------------------------------------------------
-constexpr int BG_TW = 64, BG_TH = 16, BG_MAXR = 7;
+constexpr int BG_TW = 64, BG_TH = 32, BG_MAXR = 7;
 struct BlurGrayArgs {
     const unsigned char *src;   // n_frames x rows x (cols*3) interleaved BGR
     long long src_plane, src_pitch;
     unsigned char *dst;         // n_frames x rows x cols
     long long dst_plane, dst_pitch;
-    int H, W, r;                // r = ksize / 2
-    int q[2 * BG_MAXR + 1];     // integer kernel, q[j + r] for tap j in [-r, r]
+    int H, W;
+    int q[2 * BG_MAXR + 1];     // integer kernel, q[j] for tap j - R
     int gx, gy;
 };
 
+// R = ksize / 2.  Three phases per 64 x 32 tile: (0) the BGR tile + apron is de-interleaved into planar byte
+// rows in LDS (reflect-101 folded into the gather); (1) row pass, 4 adjacent outputs per work item from
+// (4 + 2R) bytes read as dwords; (2) column pass, 4 vertically adjacent outputs of all three channels per
+// thread from (4 + 2R) LDS rows, rounding, BGR2GRAY, byte stores (64 consecutive bytes per wave and row).
+template <int R>
 __global__ __launch_bounds__(256) void blur_gray_kernel(BlurGrayArgs a)
 {
-    constexpr int IW = BG_TW + 2 * BG_MAXR, IH = BG_TH + 2 * BG_MAXR;
-    __shared__ unsigned char s_in[IH][IW * 3 + 2];
-    __shared__ int s_row[IH][BG_TW * 3];
+    constexpr int IW = BG_TW + 2 * R, IH = BG_TH + 2 * R;
+    constexpr int IWP = (IW + 3) / 4 * 4 + 4;           // padded planar byte row (dword multiple)
+    constexpr int NB = 4 + 2 * R, ND = (NB + 3) / 4;     // bytes / dwords one row-pass item reads
+    __shared__ __attribute__((aligned(16))) unsigned char s_in[3][IH][IWP];
+    __shared__ __attribute__((aligned(16))) int s_row[3][IH][BG_TW];
 
     const unsigned n = gridDim.x;
     unsigned tile = xcd_tile_id(blockIdx.x, n);
     const int bx = tile % a.gx; tile /= a.gx;
     const int by = tile % a.gy;
     const int frame = tile / a.gy;
-    const int H = a.H, W = a.W, r = a.r, t = threadIdx.x;
+    const int H = a.H, W = a.W, t = threadIdx.x;
     const int x0 = bx * BG_TW, y0 = by * BG_TH;
-    const int iw = BG_TW + 2 * r, ih = BG_TH + 2 * r;
     const unsigned char *src = a.src + (long long)frame * a.src_plane;
 
-    for (int i = t; i < ih * iw; i += 256) {                 // input tile, reflect-101
-        const int rr = i / iw, c = i - rr * iw;
-        const unsigned char *px = src + (long long)r101(y0 - r + rr, H) * a.src_pitch + (long long)r101(x0 - r + c, W) * 3;
-        s_in[rr][c * 3 + 0] = px[0]; s_in[rr][c * 3 + 1] = px[1]; s_in[rr][c * 3 + 2] = px[2];
+    // phase 0: gather + de-interleave; one wave per tile row (row index and row pointer wave-uniform),
+    // lanes over the row's bytes; a single reflection covers every column unless the image is narrower
+    // than the apron (then the general reflect-101 loop runs).  All byte loads of a thread are issued
+    // before the first LDS store (one memory latency per tile instead of one per byte).
+    {
+        constexpr int NRI = (IH + 3) / 4, NBI = (IW * 3 + 63) / 64;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+        int gofs[NBI], lofs[NBI];                            // per-lane global / LDS offsets inside a row
+#pragma unroll
+        for (int k = 0; k < NBI; ++k) {
+            const int b = min(lane + 64 * k, IW * 3 - 1);
+            const int px = b / 3, c = b - px * 3;
+            int gx = x0 - R + px;
+            gx = gx < 0 ? -gx : gx;
+            gx = gx >= W ? 2 * W - 2 - gx : gx;
+            if (gx < 0 || gx >= W) gx = r101(x0 - R + px, W);
+            gofs[k] = gx * 3 + c;
+            lofs[k] = c * (IH * IWP) + px;
+        }
+        unsigned char v[NRI][NBI];
+#pragma unroll
+        for (int it = 0; it < NRI; ++it) {
+            const int rr = min(wave + 4 * it, IH - 1);
+            const unsigned char *row = src + (long long)r101(y0 - R + rr, H) * a.src_pitch;
+#pragma unroll
+            for (int k = 0; k < NBI; ++k) v[it][k] = row[gofs[k]];
+        }
+#pragma unroll
+        for (int it = 0; it < NRI; ++it) {
+            const int rr = wave + 4 * it;
+#pragma unroll
+            for (int k = 0; k < NBI; ++k)
+                if (rr < IH && lane + 64 * k < IW * 3) (&s_in[0][0][0])[lofs[k] + rr * IWP] = v[it][k];
+        }
     }
     __syncthreads();
-    for (int i = t; i < ih * BG_TW * 3; i += 256) {          // row pass (every channel of every tile row)
-        const int rr = i / (BG_TW * 3), xc = i - rr * (BG_TW * 3);
-        int sum = 0;
-        for (int j = 0; j <= 2 * r; ++j) sum += a.q[j] * (int)s_in[rr][xc + 3 * j];
-        s_row[rr][xc] = sum;
+    for (int i = t; i < 3 * IH * (BG_TW / 4); i += 256) {    // phase 1: row pass, 8U -> 32S
+        const int g = i % (BG_TW / 4), cr = i / (BG_TW / 4);
+        const int rr = cr % IH, c = cr / IH;
+        const unsigned *w = reinterpret_cast<const unsigned *>(&s_in[c][rr][4 * g]);
+        unsigned d[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) d[k] = w[k];
+        int o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int v = (int)((d[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k - e >= 0 && k - e <= 2 * R) o[e] += __mul24(a.q[k - e], v);   // 24-bit multiply: full rate
+        }
+        *reinterpret_cast<int4 *>(&s_row[c][rr][4 * g]) = make_int4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
-    for (int i = t; i < BG_TH * BG_TW; i += 256) {           // column pass + BGR2GRAY
-        const int yy = i / BG_TW, xx = i - yy * BG_TW;
-        const int y = y0 + yy, x = x0 + xx;
-        if (y >= H || x >= W) continue;
-        int px[3];
+    for (int i = t; i < BG_TW * (BG_TH / 4); i += 256) {     // phase 2: column pass + BGR2GRAY
+        const int xx = i % BG_TW, yg = i / BG_TW;
+        const int x = x0 + xx;
+        int px[4][3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            int sum = 0;                                     // <= 255 * 65536: fits
-            for (int j = 0; j <= 2 * r; ++j) sum += a.q[j] * s_row[yy + j][xx * 3 + c];
-            int q = sum >> 16;
-            const int rem = sum & 0xFFFF;
-            if (rem > 0x8000 || (rem == 0x8000 && (q & 1))) ++q;
-            px[c] = min(max(q, 0), 255);
+            int acc[4] = {0, 0, 0, 0};                       // <= 255 * 65536: fits
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int v = s_row[c][4 * yg + k][xx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k - e >= 0 && k - e <= 2 * R) acc[e] += __mul24(a.q[k - e], v);   // both < 2^17
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int q = acc[e] >> 16;
+                const int rem = acc[e] & 0xFFFF;
+                if (rem > 0x8000 || (rem == 0x8000 && (q & 1))) ++q;      // half to even
+                px[e][c] = min(max(q, 0), 255);
+            }
         }
-        a.dst[(long long)frame * a.dst_plane + (long long)y * a.dst_pitch + x] =
-            (unsigned char)((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14);
+        if (x < W) {
+            unsigned char *d = a.dst + (long long)frame * a.dst_plane + x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int y = y0 + 4 * yg + e;
+                if (y < H)
+                    d[(long long)y * a.dst_pitch] =
+                        (unsigned char)((px[e][0] * 1868 + px[e][1] * 9617 + px[e][2] * 4899 + 8192) >> 14);
+            }
+        }
     }
 }
 
@@ -478,11 +578,8 @@ __global__ __launch_bounds__(256) void frame_diff_kernel(FrameDiffArgs a)
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, p = blockIdx.z;
     if (x >= a.W) return;
     const long long si = (long long)p * a.src_plane + (long long)y * a.src_pitch + x;
-    const float ta = __fmul_rn((float)a.cur[si], 1.0f);
-    const float tb = __fmul_rn((float)a.prev[si], a.beta);
-    const float tt = __fadd_rn(__fadd_rn(ta, tb), 0.0f);
-    const int v = __float2int_rn(tt);
-    a.dst[(long long)p * a.dst_plane + (long long)y * a.dst_pitch + x] = (unsigned char)min(max(v, 0), 255);
+    a.dst[(long long)p * a.dst_plane + (long long)y * a.dst_pitch + x] =
+        (unsigned char)frame_diff_px(a.cur[si], a.prev[si], a.beta);
 }
 
 // ------------------------------------------------------------------------------------------------

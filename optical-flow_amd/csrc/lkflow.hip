@@ -703,9 +703,9 @@ int lkflow_u8_to_f64_dev(lkflow_ctx *ctx, const unsigned char *src, double *dst,
     return LKFLOW_OK;
 }
 
-int lkflow_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *src, size_t src_ps, int n_planes, int rows,
-                           int cols, size_t src_step_bytes, int thresh, double *dst, size_t dst_ps,
-                           size_t dst_step_bytes, void *stream)
+static int edge_map_launch(lkflow_ctx *ctx, const unsigned char *src, const unsigned char *prev, double rate,
+                           size_t src_ps, int n_planes, int rows, int cols, size_t src_step_bytes, int thresh,
+                           double *dst, size_t dst_ps, size_t dst_step_bytes, void *stream)
 {
     if (!ctx || !src || !dst || rows < 1 || cols < 1 || n_planes < 1) return LKFLOW_E_ARG;
     if (src_step_bytes < (size_t)cols || dst_step_bytes < (size_t)cols * 8 || dst_step_bytes % 8 || dst_ps % 8)
@@ -713,7 +713,8 @@ int lkflow_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *src, size_t src
     int rc = set_device(ctx);
     if (rc) return rc;
     lk::EdgeArgs a{};
-    a.src = src; a.src_plane = (long long)src_ps; a.src_pitch = (long long)src_step_bytes;
+    a.src = src; a.prev = prev; a.beta = (float)(-rate);
+    a.src_plane = (long long)src_ps; a.src_pitch = (long long)src_step_bytes;
     a.dst = Planes{dst, (long long)(dst_ps / 8), (long long)(dst_step_bytes / 8)};
     a.H = rows; a.W = cols; a.thresh = thresh;
     a.gx = (cols + lk::EM_TW - 1) / lk::EM_TW; a.gy = (rows + lk::EM_TH - 1) / lk::EM_TH;
@@ -722,6 +723,23 @@ int lkflow_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *src, size_t src
     hipLaunchKernelGGL(lk::edge_map_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
+}
+
+int lkflow_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *src, size_t src_ps, int n_planes, int rows,
+                           int cols, size_t src_step_bytes, int thresh, double *dst, size_t dst_ps,
+                           size_t dst_step_bytes, void *stream)
+{
+    return edge_map_launch(ctx, src, nullptr, 0.0, src_ps, n_planes, rows, cols, src_step_bytes, thresh, dst, dst_ps,
+                           dst_step_bytes, stream);
+}
+
+int lkflow_diff_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *cur, const unsigned char *prev, size_t src_ps,
+                                int n_planes, int rows, int cols, size_t src_step_bytes, double rate, int thresh,
+                                double *dst, size_t dst_ps, size_t dst_step_bytes, void *stream)
+{
+    if (!prev) return LKFLOW_E_ARG;
+    return edge_map_launch(ctx, cur, prev, rate, src_ps, n_planes, rows, cols, src_step_bytes, thresh, dst, dst_ps,
+                           dst_step_bytes, stream);
 }
 
 int lkflow_blur_gray_bgr8_dev(lkflow_ctx *ctx, const unsigned char *bgr, size_t src_ps, int n_frames, int rows,
@@ -753,11 +771,16 @@ int lkflow_blur_gray_bgr8_dev(lkflow_ctx *ctx, const unsigned char *bgr, size_t 
     }
     a.src = bgr; a.src_plane = (long long)src_ps; a.src_pitch = (long long)src_step_bytes;
     a.dst = gray; a.dst_plane = (long long)dst_ps; a.dst_pitch = (long long)dst_step_bytes;
-    a.H = rows; a.W = cols; a.r = ksize / 2;
+    a.H = rows; a.W = cols;
     a.gx = (cols + lk::BG_TW - 1) / lk::BG_TW; a.gy = (rows + lk::BG_TH - 1) / lk::BG_TH;
     const long long n = (long long)a.gx * a.gy * n_frames;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
-    hipLaunchKernelGGL(lk::blur_gray_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+    switch (ksize / 2) {
+#define BG_CASE(RR) case RR: hipLaunchKernelGGL(lk::blur_gray_kernel<RR>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a); break;
+        BG_CASE(0) BG_CASE(1) BG_CASE(2) BG_CASE(3) BG_CASE(4) BG_CASE(5) BG_CASE(6) BG_CASE(7)
+#undef BG_CASE
+        default: return LKFLOW_E_WIN;
+    }
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }

@@ -68,6 +68,7 @@ SIGNATURES = {
     "lkflow_blur_gray_bgr8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _i, _d, _vp, _sz, _sz, _vp]),
     "lkflow_frame_diff_u8_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _vp, _sz, _sz, _vp]),
     "lkflow_edge_map_u8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _i, _vp, _sz, _sz, _vp]),
+    "lkflow_diff_edge_map_u8_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _i, _vp, _sz, _sz, _vp]),
     "lkflow_flow_centroid_f64_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _vp, _vp]),
 }
 
@@ -269,6 +270,22 @@ class Context:
         """frames: [F, H, W] float64 CUDA tensor -> flow of the F-1 consecutive pairs."""
         return self.compute_batch(frames[:-1], frames[1:], levels, win, out=out, stream=stream)
 
+    def compute_video_strict(self, frames, levels, win=3, stream=None):
+        """The reference's video loop taken literally (ParallelVideoPyr.cpp:832-843): the level-0 warp
+        overwrites both inputs of a pair and `prevDiff = diff` hands the WARPED frame to the next pair, so
+        the pairs form a serial chain.  frames: [F, H, W] float64 CUDA tensor, overwritten exactly as the
+        reference overwrites its frames.  Returns (U, V) [F-1, H, W].  One launch sequence per pair
+        (no batching is possible); use compute_video() when pairs should be independent."""
+        torch = _torch()
+        _check_dev(frames, "frames")
+        F, H, W = frames.shape
+        U = torch.empty((F - 1, H, W), dtype=torch.float64, device=frames.device)
+        V = torch.empty_like(U)
+        for k in range(F - 1):
+            self.compute_batch(frames[k:k + 1], frames[k + 1:k + 2], levels, win, out=(U[k:k + 1], V[k:k + 1]),
+                               flags=LKFLOW_MUTATE_INPUTS, stream=stream)
+        return U, V
+
     def lk_batch(self, img1, img2, win=3, stream=None):
         torch = _torch()
         _check_dev(img1, "img1"); _check_dev(img2, "img2")
@@ -365,8 +382,21 @@ class Context:
         """The video loop's whole per-frame chain after the resize (ParallelVideoPyr.cpp:786-813):
         [F,H,W,3] uint8 BGR frames -> [F-1,H,W] float64 edge images, the inputs of the hot call
         (consecutive edge images form the F-2 frame pairs)."""
-        gray = self.blur_gray(bgr_u8, ksize, sigma, stream)
-        return self.edge_map(self.frame_diff(gray, rate, stream), thresh, stream)
+        return self.diff_edge_map(self.blur_gray(bgr_u8, ksize, sigma, stream), rate, thresh, stream)
+
+    def diff_edge_map(self, gray_u8, rate=0.3, thresh=10, stream=None):
+        """frame_diff() + edge_map() fused (the difference image is never stored): [F,H,W] uint8 gray frames
+        -> [F-1,H,W] float64 edge images."""
+        torch = _torch()
+        assert gray_u8.is_cuda and gray_u8.dtype == torch.uint8 and gray_u8.dim() == 3 and gray_u8.stride(-1) == 1
+        F, H, W = gray_u8.shape
+        assert F >= 2
+        out = torch.empty((F - 1, H, W), dtype=torch.float64, device=gray_u8.device)
+        self._chk(lib().lkflow_diff_edge_map_u8_dev(self._h, gray_u8[1:].data_ptr(), gray_u8.data_ptr(),
+                                                    gray_u8.stride(0), F - 1, H, W, gray_u8.stride(1), float(rate),
+                                                    int(thresh), out.data_ptr(), out.stride(0) * 8,
+                                                    out.stride(1) * 8, _stream_ptr(stream)))
+        return out
 
     def edge_map(self, diff_u8, thresh=10, stream=None):
         """[N,H,W] uint8 frame differences -> [N,H,W] float64 edge images (ParallelVideoPyr.cpp:803-813:

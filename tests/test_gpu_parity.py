@@ -392,7 +392,9 @@ def test_preprocess_chain_feeds_the_hot_call(gpu_ctx, oracle, torch):
     h, w, F = 64, 96, 4
     base = synth.video(F, h, w, seed=5)                             # [F,h,w] float64 in [0,1]
     bgr = np.stack([np.clip(base * s, 0, 1) for s in (255, 200, 150)], axis=-1).astype(np.uint8)
-    edges = host(gpu_ctx.preprocess_bgr(dev(torch, bgr)))
+    edges = host(gpu_ctx.preprocess_bgr(dev(torch, bgr)))                       # blur/gray + fused diff/edge map
+    g = gpu_ctx.blur_gray(dev(torch, bgr))
+    assert np.array_equal(host(gpu_ctx.edge_map(gpu_ctx.frame_diff(g, 0.3), 10)), edges)   # unfused == fused
     gray = [oracle.blur_gray_bgr8(bgr[k]) for k in range(F)]
     want = [oracle.edge_map_u8(oracle.frame_diff_u8(gray[k + 1], gray[k], 0.3), 10) for k in range(F - 1)]
     for k in range(F - 1):
@@ -402,3 +404,20 @@ def test_preprocess_chain_feeds_the_hot_call(gpu_ctx, oracle, torch):
         uo, vo = oracle.coarse_to_fine(want[p], want[p + 1], 3, 5)
         scale = max(1.0, np.abs(uo).max(), np.abs(vo).max())
         assert np.abs(host(U[p]) - uo).max() <= TOL * scale and np.abs(host(V[p]) - vo).max() <= TOL * scale
+
+
+def test_video_strict_chain_matches_oracle(gpu_ctx, oracle, torch):
+    """ParallelVideoPyr.cpp:832-843 literally: every pair's inputs are overwritten by their level-0 warp and
+    the warped `diff` becomes the next pair's `prevDiff` (a serial chain through the whole stream)."""
+    import synth
+    frames = synth.video(4, 64, 96, seed=11)
+    ref = [f.copy() for f in frames]
+    want = [oracle.coarse_to_fine(ref[k], ref[k + 1], 3, 5, mutate=True) for k in range(3)]   # mutates ref[k], ref[k+1]
+    d = dev(torch, frames)
+    U, V = gpu_ctx.compute_video_strict(d, 3, 5)
+    for k in range(3):
+        assert np.abs(host(U[k]) - want[k][0]).max() <= TOL and np.abs(host(V[k]) - want[k][1]).max() <= TOL
+    for k in range(4):                                             # frames end up warped exactly like the oracle's
+        assert np.abs(host(d[k]) - ref[k]).max() <= TOL
+    Ui, Vi = gpu_ctx.compute_video(dev(torch, frames), 3, 5)       # independent pairs differ from the chain after pair 0
+    assert np.array_equal(host(Ui[0]), host(U[0])) and not np.array_equal(host(Ui[1]), host(U[1]))
