@@ -585,12 +585,32 @@ __global__ __launch_bounds__(256) void frame_diff_kernel(FrameDiffArgs a)
 // ------------------------------------------------------------------------------------------------
 // convertTo(CV_64FC1, 1.0/255)  (SerialPyr.cpp:237)
 // ------------------------------------------------------------------------------------------------
+// A wave converts 512 consecutive bytes per iteration as four (2-byte load, 16-byte store) rounds, so that
+// every load covers 128 contiguous bytes and every store 1 KiB contiguous; the unaligned head / tail
+// (src odd or n not a multiple of 2) go through the scalar path.
 __global__ __launch_bounds__(256) void u8_to_f64_kernel(const unsigned char *src, double *dst,
                                                         size_t n)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool aligned = (reinterpret_cast<size_t>(src) & 1) == 0 && (reinterpret_cast<size_t>(dst) & 15) == 0;
+    const size_t npair = aligned ? n / 2 : 0;
+    const unsigned short *s2 = reinterpret_cast<const unsigned short *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) dst[i] = (double)src[i] * (1.0 / 255);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < npair; i += 4 * stride) {
+        unsigned short v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = s2[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            d2[i + k * stride] = make_double2((double)(v[k] & 0xFF) * (1.0 / 255), (double)(v[k] >> 8) * (1.0 / 255));
+    }
+    for (; i < npair; i += stride) {
+        const unsigned short v = s2[i];
+        d2[i] = make_double2((double)(v & 0xFF) * (1.0 / 255), (double)(v >> 8) * (1.0 / 255));
+    }
+    for (size_t j = 2 * npair + (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
+        dst[j] = (double)src[j] * (1.0 / 255);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -598,17 +618,33 @@ __global__ __launch_bounds__(256) void u8_to_f64_kernel(const unsigned char *src
 // |flow| >= thresh.  Sums are integers < 2^53, accumulated in fp64 -> exact in any order.
 // out[3*pair + {0,1,2}] must be zeroed by the caller (the launcher does it).
 // ------------------------------------------------------------------------------------------------
+// The reference tests sqrt(u*u + v*v) < thresh; sqrt is monotonic and correctly rounded, so the launcher
+// passes thresh2 = the smallest double whose square root is >= thresh and the kernel compares the sum of
+// squares against it (same decisions bit for bit, no fp64 square root per pixel).
 __global__ __launch_bounds__(256) void centroid_kernel(CPlanes U, CPlanes V, int H, int W,
-                                                       double thresh, double *out)
+                                                       double thresh2, double *out)
 {
     const int pair = blockIdx.z;
     const double *u = U.at(pair), *v = V.at(pair);
     double c = 0, sx = 0, sy = 0;
-    for (int y = blockIdx.y; y < H; y += gridDim.y) {
-        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < W; x += gridDim.x * blockDim.x) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < W) {
+        const double xd = (double)x;
+        int y = blockIdx.y;
+        for (; y + 3 * (int)gridDim.y < H; y += 4 * gridDim.y) {      // four independent rows in flight
+            double xf[4], yf[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                xf[k] = u[(long long)(y + k * gridDim.y) * U.pitch + x];
+                yf[k] = v[(long long)(y + k * gridDim.y) * V.pitch + x];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!(xf[k] * xf[k] + yf[k] * yf[k] < thresh2)) { c += 1.0; sx += xd; sy += (double)(y + k * gridDim.y); }
+        }
+        for (; y < H; y += gridDim.y) {
             const double xf = u[(long long)y * U.pitch + x], yf = v[(long long)y * V.pitch + x];
-            const double val = sqrt(xf * xf + yf * yf);
-            if (!(val < thresh)) { c += 1.0; sx += (double)x; sy += (double)y; }
+            if (!(xf * xf + yf * yf < thresh2)) { c += 1.0; sx += xd; sy += (double)y; }
         }
     }
 #pragma unroll

@@ -7,6 +7,7 @@
 // call into a HIP graph after lkflow_ctx_reserve().
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -815,10 +816,21 @@ int lkflow_flow_centroid_f64_dev(lkflow_ctx *ctx, const double *U, const double 
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(ctx, hipMemsetAsync(out, 0, (size_t)n_pairs * 3 * sizeof(double), s));
     const long long ps = uv_ps / 8, st = uv_step_bytes / 8;
+    // smallest double whose (correctly rounded) square root is >= thresh: sqrt(s) < thresh <=> s < thresh2.
+    // thresh <= 0 or NaN: the reference's `val < thresh` is never true for val >= 0 -> every pixel counts.
+    double thresh2;
+    if (!(thresh > 0.0)) thresh2 = -INFINITY;
+    else if (std::isinf(thresh)) thresh2 = INFINITY;
+    else {
+        thresh2 = thresh * thresh;
+        if (std::isinf(thresh2)) thresh2 = DBL_MAX;
+        while (thresh2 > 0.0 && std::sqrt(thresh2) >= thresh) thresh2 = std::nextafter(thresh2, 0.0);
+        while (std::sqrt(thresh2) < thresh) thresh2 = std::nextafter(thresh2, INFINITY);
+    }
     int gx = (cols + 255) / 256;
-    int gy = rows < 64 ? rows : 64;
+    int gy = rows < 32 ? rows : 32;
     hipLaunchKernelGGL(lk::centroid_kernel, dim3(gx, gy, n_pairs), dim3(256), 0, s, CPlanes{U, ps, st},
-                       CPlanes{V, ps, st}, rows, cols, thresh, out);
+                       CPlanes{V, ps, st}, rows, cols, thresh2, out);
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }

@@ -237,6 +237,33 @@ def test_flow_centroid_matches_oracle(gpu_ctx, oracle, torch):
         assert tuple(out[p]) == (float(c), sx, sy)
 
 
+@pytest.mark.parametrize("thresh", [20.0, 3.3, 1e-3, 0.0, -1.0, float("inf"), float("nan")])
+def test_flow_centroid_threshold_boundary(gpu_ctx, oracle, torch, thresh):
+    """The kernel compares u*u+v*v with a pre-squared threshold instead of taking sqrt per pixel: the decisions
+    must be those of `sqrt(u*u+v*v) < thresh` (ParallelVideoPyr.cpp:856-858) exactly, also within a few ulps of
+    the circle |flow| == thresh, and for degenerate thresholds / non-finite flow."""
+    rng = np.random.default_rng(3)
+    r = thresh if np.isfinite(thresh) and thresh > 0 else 1.0
+    th = rng.uniform(0, 2 * np.pi, (2, 64, 200))
+    eps = rng.integers(-3, 4, th.shape) * np.spacing(r)            # radii within +-3 ulp of the threshold
+    u, v = (r + eps) * np.cos(th), (r + eps) * np.sin(th)
+    u[0, 0, :4] = (r, -r, 0.0, 0.0); v[0, 0, :4] = (0.0, 0.0, r, -r)  # exactly on the circle
+    u[1, 1, :3] = (np.nan, np.inf, 0.0); v[1, 1, :3] = (0.0, 1.0, -np.inf)
+    out = host(gpu_ctx.flow_centroid(dev(torch, u), dev(torch, v), thresh))
+    for p in range(2):
+        c, sx, sy = oracle.flow_centroid(u[p], v[p], thresh)
+        assert tuple(out[p]) == (float(c), sx, sy)
+
+
+@pytest.mark.parametrize("n,offset", [(1, 0), (2, 0), (7, 1), (4096 + 5, 0), (100003, 1), (640 * 448, 2)])
+def test_u8_conversion_ragged(gpu_ctx, oracle, torch, n, offset):
+    """Odd lengths / odd source addresses take the scalar head-tail path of the vectorised kernel."""
+    rng = np.random.default_rng(n)
+    buf = torch.from_numpy(rng.integers(0, 256, n + offset).astype(np.uint8)).cuda()
+    src = buf[offset:]
+    assert np.array_equal(host(gpu_ctx.u8_to_f64(src)), oracle.u8_to_f64(host(src)))
+
+
 # ------------------------------------------------------------------------------- error behaviour
 def test_error_codes(gpu_ctx, lkflow, torch):
     a = torch.zeros((1, 64, 96), dtype=torch.float64, device="cuda")
