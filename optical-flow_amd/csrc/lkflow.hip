@@ -7,6 +7,7 @@
 // call into a HIP graph after lkflow_ctx_reserve().
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -209,7 +210,7 @@ inline int pick_tile_rows(int H, int R, long long blocks_per_strip, long long sl
 }
 
 template <int WIN, int TX>
-void launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
+int launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
 {
     constexpr int R = WIN / 2;
     constexpr int xo = TX - 2 * R;
@@ -220,6 +221,14 @@ void launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipSt
         th = pick_tile_rows(a.H, R, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
     }
     if (th > a.H) th = a.H;
+    {   // the kernel addresses a strip with 32-bit byte offsets from its first row: cap the strip height
+        long long pmax = a.i1.pitch;
+        if (a.u.pitch > pmax) pmax = a.u.pitch;
+        if (a.v.pitch > pmax) pmax = a.v.pitch;
+        const long long cap = 0x7fffffffLL / (pmax * 8) - 2 * R - 8;
+        if (cap < 1) return LKFLOW_E_ARG;
+        if (th > cap) th = (int)cap;
+    }
     a.th = th;
     dim3 grid(gx, (a.H + th - 1) / th, pairs);
 #ifdef LK3_STAMPS
@@ -235,7 +244,7 @@ void launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipSt
             (void)hipMemcpy(h.data(), dbuf, dn * 8, hipMemcpyDeviceToHost);
             FILE *f = fopen(getenv("LKFLOW_STAMPS_OUT"), "wb");
             if (f) { fwrite(h.data(), 8, dn, f); fclose(f); }
-            return;
+            return LKFLOW_OK;
         }
     }
 #endif
@@ -243,13 +252,14 @@ void launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipSt
         hipLaunchKernelGGL((lk::lk_march3_kernel<WIN, TX, true>), grid, dim3(TX), 0, s, a);
     else
         hipLaunchKernelGGL((lk::lk_march3_kernel<WIN, TX, false>), grid, dim3(TX), 0, s, a);
+    return LKFLOW_OK;
 }
 
 template <int TX>
 int launch_lk3(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, int win, hipStream_t s)
 {
     switch (win) {
-#define LK_CASE(WN) case WN: launch_lk3_win<WN, TX>(ctx, a, has_up, pairs, s); break;
+#define LK_CASE(WN) case WN: return launch_lk3_win<WN, TX>(ctx, a, has_up, pairs, s);
 #ifdef LKFLOW_FAST_BUILD   /* A/B experiment builds: only the windows the goldens / headline use */
         LK_CASE(3) LK_CASE(5) LK_CASE(9) LK_CASE(15)
 #else
@@ -281,8 +291,10 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
         const int R = win / 2;
         const long long c128 = (long long)((a.W + (128 - 2 * R) - 1) / (128 - 2 * R)) * 128;
         const long long c256 = (long long)((a.W + (256 - 2 * R) - 1) / (256 - 2 * R)) * 256;
-        int rc = (win <= 15 && c128 * 100 <= c256 * 108) ? launch_lk3<128>(ctx, a, has_up, pairs, win, s)
-                                                          : launch_lk3<256>(ctx, a, has_up, pairs, win, s);
+        bool use128 = win <= 15 && c128 * 100 <= c256 * 108;
+        { static const int e = getenv("LKFLOW_LK_TX") ? atoi(getenv("LKFLOW_LK_TX")) : 0;   // debug knob
+          if (e == 128) use128 = true; else if (e == 256) use128 = false; }
+        int rc = use128 ? launch_lk3<128>(ctx, a, has_up, pairs, win, s) : launch_lk3<256>(ctx, a, has_up, pairs, win, s);
 #endif
         if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
@@ -327,6 +339,8 @@ int launch_warp(lkflow_ctx *ctx, CPlanes i1, CPlanes i2, int H, int W, CPlanes c
     a.th = LK_WARP_TH;                           // even; two rows per iteration
     { static const int e = getenv("LKFLOW_WARP_TH") ? atoi(getenv("LKFLOW_WARP_TH")) : 0; if (e > 0) a.th = e & ~1; }
     a.gx = (W + 255) / 256; a.gy = (H + a.th - 1) / a.th;
+    if ((long long)(a.th + 2) * 8 * std::max(std::max(o1.pitch, o2.pitch), std::max(cu.pitch, cv.pitch)) > 0x7fffffffLL)
+        return LKFLOW_E_ARG;                      // strip-relative 32-bit byte offsets
     const long long n = (long long)a.gx * a.gy * pairs;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
     hipLaunchKernelGGL(lk::warp_kernel, dim3((unsigned)n), dim3(256), 0, s, a);

@@ -448,3 +448,30 @@ def test_video_strict_chain_matches_oracle(gpu_ctx, oracle, torch):
         assert np.abs(host(d[k]) - ref[k]).max() <= TOL
     Ui, Vi = gpu_ctx.compute_video(dev(torch, frames), 3, 5)       # independent pairs differ from the chain after pair 0
     assert np.array_equal(host(Ui[0]), host(U[0])) and not np.array_equal(host(Ui[1]), host(U[1]))
+
+
+def test_planes_larger_than_4GiB(gpu_ctx, lkflow, torch):
+    """Maximum sizes: a 24000 x 24000 fp64 plane is 4.6 GB, so row/strip addresses do not fit 32-bit byte
+    offsets from the plane base.  The marching kernel (strip-relative buffer descriptors) must agree with the
+    per-pixel kernel (plain 64-bit pointers) everywhere, in particular in the rows beyond the 4 GiB mark, and
+    the 2-level path must run through pyrDown / warp on such planes."""
+    n = 24000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.rand((1, n, n), dtype=torch.float64, device="cuda", generator=g)
+    b = torch.roll(a, shifts=(1, -1), dims=(1, 2)) * 0.5 + a * 0.5
+    u, v = gpu_ctx.lk_batch(a, b, 5)
+    gpu_ctx.set_option(lkflow.LKFLOW_OPT_IMPL, 1)
+    try:
+        un, vn = gpu_ctx.lk_batch(a, b, 5)
+    finally:
+        gpu_ctx.set_option(lkflow.LKFLOW_OPT_IMPL, 0)
+    for got, want in ((u, un), (v, vn)):                            # 576 M noise pixels: a few are ill-conditioned,
+        err = (got - want).abs_().div_(want.abs().clamp_(min=1.0))   # so the bar is relative for |flow| > 1
+        assert err.max().item() <= TOL
+        del err
+    assert u[0, -3:].abs().max().item() > 0 and torch.isfinite(u).all().item()
+    del un, vn
+    U, V = gpu_ctx.compute_batch(a, b, 2, 3)
+    assert torch.isfinite(U).all().item() and torch.isfinite(V).all().item()
+    lo, hi = U[0, :64], U[0, -64:]                                   # both ends of the plane were written
+    assert lo.abs().max().item() > 0 and hi.abs().max().item() > 0
