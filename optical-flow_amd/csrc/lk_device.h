@@ -185,7 +185,10 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, int voff, int s
     lk_u2 v;
     v.x = (unsigned)__double2loint(d);
     v.y = (unsigned)__double2hiint(d);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+    // aux = 2 ("nt"): streaming store.  Every plane the pipeline writes is consumed by a LATER kernel, long
+    // after 2 GB of other traffic, so keeping the lines in L2 / Infinity Cache only evicts useful ones
+    // (A/B on 32 x 1080p: warp 0.595 -> 0.572 ms, whole step -1.7 %).
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 2);
 }
 
 }  // namespace lk

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
         const double h3 = hf(p3x, p3y), h4 = hf(p4x, p4y), h5 = hf(p5x, p5y), h6 = hf(p6x, p6y);
         const double o0 = (h2 * 6 + (h1 + h3) * 4 + h0 + h4) * (1.0 / 256);
         const double o1 = (h4 * 6 + (h3 + h5) * 4 + h2 + h6) * (1.0 / 256);
-        if (out_lane) { d[0] = o0; d[dp] = o1; }
+        if (out_lane) { d[0] = o0; d[dp] = o1; }          // (cached: the next level and LK re-read it soon)
         d += 2 * dp;
         h0 = h4; h1 = h5; h2 = h6;
     }
