@@ -73,6 +73,13 @@ for (h, w, lv, win) in [(448, 640, 7, 3), (40, 56, 3, 15), (8, 8, 4, 5), (2, 2, 
     u, v = np.empty((h, w)), np.empty((h, w))
     rc = L.lko_coarse_to_fine(a.ctypes.data_as(dp), b.ctypes.data_as(dp), h, w, lv, win, u.ctypes.data_as(dp), v.ctypes.data_as(dp))
     assert rc == 0 and np.isfinite(u).all()
+bp = ctypes.POINTER(ctypes.c_ubyte)
+for (h, w, k, sg) in [(1, 1, 9, 1.5), (3, 4, 9, 1.5), (9, 2, 15, 3.0), (40, 50, 3, 0.8)]:      # f2 chain, tiny / ragged shapes
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8); g = np.empty((h, w), np.uint8)
+    L.lko_blur_gray_bgr8(img.ctypes.data_as(bp), h, w, k, ctypes.c_double(sg), g.ctypes.data_as(bp))
+    d = np.empty((h, w), np.uint8); e = np.empty((h, w))
+    L.lko_frame_diff_u8(g.ctypes.data_as(bp), img[..., 0].copy().ctypes.data_as(bp), ctypes.c_long(h * w), ctypes.c_double(0.3), d.ctypes.data_as(bp))
+    L.lko_edge_map_u8(d.ctypes.data_as(bp), h, w, 10, e.ctypes.data_as(dp))
 print("asan-ok")
 """
     asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
