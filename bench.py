@@ -125,6 +125,34 @@ def preprocess_rate(ctx, torch, device, frames=33, side=1080, steps=20):
             "note": "rank 0 only, extra measurement after the timed region; uint8 BGR in -> CV_64F edge images out"}
 
 
+def video_pipeline_rate(lkf, torch, device, frames=50, side=1080, levels=4, win=3, steps=10):
+    """Extra, NOT the headline: the reference's whole per-frame loop after the resize at its own working shape
+    (ParallelVideoPyr.cpp:786-873; 1080 x 1080, getMaxLayer = 4 levels, 3 x 3 window), device-resident:
+    uint8 BGR frames -> blur/gray -> difference + edge map -> dense pyramidal LK on consecutive edge images
+    (independent pairs, batched) -> |flow| >= 20 centroid sums; only 3 doubles per pair leave the GPU."""
+    ctx = lkf.Context(device)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    bgr = torch.randint(0, 256, (frames, side, side, 3), dtype=torch.uint8, generator=g).to(f"cuda:{device}")
+    ctx.reserve(side, side, levels, frames - 2)
+
+    def step():
+        edges = ctx.preprocess_bgr(bgr)                      # [F-1, H, W] float64
+        U, V = ctx.compute_video(edges, levels, win)         # F-2 pairs
+        return ctx.flow_centroid(U, V, 20.0)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    out.cpu()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.close()
+    return {"frames": frames, "shape": [side, side, 3], "pyr_levels": levels, "win": win,
+            "ms_per_batch": round(dt * 1e3, 3), "frames_per_s": round(frames / dt, 1),
+            "note": "rank 0 only, extra measurement after the timed region; includes the 3-scalar D2H copy"}
+
+
 def cpu_baseline(cols, rows, levels, win, budget_s=20.0):
     """Times oracle/lk_cpu_omp.c (the restated ParallelVideoPyr.cpp CPU path) on this host."""
     import synth
@@ -334,6 +362,7 @@ def main():
             out["pipelined"] = pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, local_rank, world)
         if world == 1 and not args.no_extras:
             out["preprocess"] = preprocess_rate(ctx, torch, local_rank)
+            out["video_pipeline"] = video_pipeline_rate(lkf, torch, local_rank)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(cols, rows, levels, win)
         print(json.dumps(out), flush=True)
