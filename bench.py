@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=0, help="frame pairs per step per GPU")
     ap.add_argument("--config", default="1080p", choices=sorted(CONFIGS))
+    ap.add_argument("--win", type=int, default=0, help="override the config's window (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed region (no cpu_baseline, no pipelined pass): use under rocprofv3")
@@ -219,6 +220,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cols, rows, levels, win, p_default = CONFIGS[args.config]
+    win = args.win or win
     P = args.pairs or p_default
     dev = torch.device("cuda", local_rank)
 

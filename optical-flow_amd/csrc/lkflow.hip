@@ -261,7 +261,7 @@ int launch_lk3(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, int
     switch (win) {
 #define LK_CASE(WN) case WN: return launch_lk3_win<WN, TX>(ctx, a, has_up, pairs, s);
 #ifdef LKFLOW_FAST_BUILD   /* A/B experiment builds: only the windows the goldens / headline use */
-        LK_CASE(3) LK_CASE(5) LK_CASE(9) LK_CASE(15)
+        LK_CASE(3) LK_CASE(5) LK_CASE(9) LK_CASE(13) LK_CASE(15)
 #else
         LK_CASE(3) LK_CASE(5) LK_CASE(7) LK_CASE(9) LK_CASE(11) LK_CASE(13) LK_CASE(15) LK_CASE(17)
         LK_CASE(19) LK_CASE(21) LK_CASE(23) LK_CASE(25) LK_CASE(27) LK_CASE(29) LK_CASE(31)
