@@ -30,6 +30,7 @@ CONFIGS = {
     # the reference's own shipped loop: 1080x1080 CV_64F, getMaxLayer = 4 levels, 3x3 (ParallelVideoPyr.cpp:782,831)
     "webcam": (1080, 1080, 4, 3, 48),
 }
+VIDEO_CONFIGS = ("8k", "pacman", "webcam")   # consecutive pairs of one frame sequence (BASELINE configs 3, 4 + the webcam loop)
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 
 
@@ -224,8 +225,13 @@ def main():
     P = args.pairs or p_default
     dev = torch.device("cuda", local_rank)
 
-    # synthetic translated-noise pairs generated in HBM (each rank: its own shard of the stream)
-    prev, nxt = synth.frame_pairs_torch(P, rows, cols, dev, seed=1234 + rank)
+    # synthetic translated-noise input generated in HBM (each rank: its own shard).  BASELINE configs 3 and 4 are
+    # STREAMS (consecutive pairs of one frame sequence): P+1 frames, pair p = frames p, p+1; the others are pairs.
+    if args.config in VIDEO_CONFIGS:
+        frames = synth.video_torch(P + 1, rows, cols, dev, seed=1234 + rank)
+        prev, nxt = frames[:-1], frames[1:]
+    else:
+        prev, nxt = synth.frame_pairs_torch(P, rows, cols, dev, seed=1234 + rank)
     U = torch.empty_like(prev)
     V = torch.empty_like(prev)
     ctx = lkf.Context(local_rank)
@@ -325,8 +331,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{cols}x{rows} synthetic translated-noise frame pairs, {levels} levels, "
-                            f"{win}x{win} window, {P} independent pairs per step per GPU (device-resident)",
+                "workload": (f"{cols}x{rows} synthetic translated-noise frame stream, {levels} levels, {win}x{win} "
+                             f"window, {P + 1} frames = {P} consecutive pairs per step per GPU (device-resident)"
+                             if args.config in VIDEO_CONFIGS else
+                             f"{cols}x{rows} synthetic translated-noise frame pairs, {levels} levels, "
+                             f"{win}x{win} window, {P} independent pairs per step per GPU (device-resident)"),
                 "cols": cols, "rows": rows, "pyr_levels": levels, "win": win,
                 "pairs_per_step_per_gpu": P,
                 "parallelism": f"frame-pair sharding x{world} (no data-path collective)",

@@ -509,15 +509,23 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
     const std::vector<Level> &lv = ctx->lv;
     const long long step = (long long)(step_bytes / 8);
 
+    // A video batch (pair p = frames p, p+1 of one buffer: next == prev + one frame stride, the addressing the
+    // header documents) shares every interior frame between two pairs: its pyramid is built ONCE, P+1 planes per
+    // level instead of 2P, and "frame 2" of pair p is simply plane p+1.  (The pyramids are never written after
+    // they are built -- warps go to their own planes -- so sharing cannot change a result.)
+    const bool video = P > 1 && prev_ps == next_ps && prev_ps >= (size_t)rows * step_bytes &&
+                       reinterpret_cast<const char *>(next) == reinterpret_cast<const char *>(prev) + prev_ps;
+    const long long f2 = video ? 1 : P;          // plane offset of a pair's second frame inside a level
+
     // image planes of frame f (0 = prev, 1 = next) at level l, original (un-warped)
     auto pyr = [&](int l, int f) -> CPlanes {
         if (l == 0) return f == 0 ? CPlanes{prev, (long long)(prev_ps / 8), step}
                                   : CPlanes{next, (long long)(next_ps / 8), step};
-        return CPlanes{arena_at(ctx, ctx->off_pyr[l] + (long long)f * P * lv[l].plane), lv[l].plane,
+        return CPlanes{arena_at(ctx, ctx->off_pyr[l] + (long long)f * f2 * lv[l].plane), lv[l].plane,
                        lv[l].pitch};
     };
     auto pyr_w = [&](int l, int f) -> Planes {
-        return Planes{arena_at(ctx, ctx->off_pyr[l] + (long long)f * P * lv[l].plane), lv[l].plane,
+        return Planes{arena_at(ctx, ctx->off_pyr[l] + (long long)f * f2 * lv[l].plane), lv[l].plane,
                       lv[l].pitch};
     };
     auto warp_w = [&](int l, int f) -> Planes {
@@ -536,12 +544,17 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
     for (int l = 1; l < L; ++l) {
         if (l == 1) {
             ProfScope ps(ctx, LKFLOW_STAGE_PYRDOWN, 1, s);
-            for (int f = 0; f < 2; ++f)
-                if ((rc = launch_pyrdown(ctx, pyr(0, f), lv[0].H, lv[0].W, pyr_w(1, f), P, s))) return rc;
+            if (video) {                                  // P+1 frames, one launch
+                if ((rc = launch_pyrdown(ctx, pyr(0, 0), lv[0].H, lv[0].W, pyr_w(1, 0), P + 1, s))) return rc;
+            } else {
+                for (int f = 0; f < 2; ++f)
+                    if ((rc = launch_pyrdown(ctx, pyr(0, f), lv[0].H, lv[0].W, pyr_w(1, f), P, s))) return rc;
+            }
         } else {
             ProfScope ps(ctx, LKFLOW_STAGE_PYRDOWN, l, s);
-            // frames 1 and 2 are adjacent in the arena: one launch over 2P planes
-            if ((rc = launch_pyrdown(ctx, pyr(l - 1, 0), lv[l - 1].H, lv[l - 1].W, pyr_w(l, 0), 2 * P, s)))
+            // the planes of a level are adjacent in the arena: one launch over 2P (video: P+1) planes
+            if ((rc = launch_pyrdown(ctx, pyr(l - 1, 0), lv[l - 1].H, lv[l - 1].W, pyr_w(l, 0),
+                                     video ? P + 1 : 2 * P, s)))
                 return rc;
         }
     }

@@ -80,3 +80,34 @@ def frame_pairs_torch(n_pairs, h, w, device, seed=1234, shift=(1.5, -0.75)):
         nxt[p] = ((1 - fy) * ((1 - fx) * a[y0][:, x0] + fx * a[y0][:, x1]) +
                   fy * ((1 - fx) * a[y1][:, x0] + fx * a[y1][:, x1]))
     return prev, nxt
+
+
+def video_torch(n_frames, h, w, device, seed=1234, shift=(1.5, -0.75)):
+    """[F,H,W] float64 frames generated on `device`: one smoothed-noise base, frame k = frame k-1 translated by
+    `shift` (bilinear, edge-clamped) -- the stream form of the synthetic workload ("video batches:
+    cumulative translation per frame").  Consecutive frames form the F-1 pairs."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    k = torch.tensor(_gauss_kernel(), dtype=torch.float64, device=device)
+    r = k.numel() // 2
+    ys = (torch.arange(h, dtype=torch.float64, device=device) - shift[1]).clamp(0, h - 1)
+    xs = (torch.arange(w, dtype=torch.float64, device=device) - shift[0]).clamp(0, w - 1)
+    y0 = ys.floor().long(); x0 = xs.floor().long()
+    y1 = (y0 + 1).clamp(max=h - 1); x1 = (x0 + 1).clamp(max=w - 1)
+    fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+    a = torch.rand((1, 1, h, w), dtype=torch.float64, device=device, generator=g)
+    a = F.conv2d(F.pad(a, (r, r, 0, 0), mode="reflect"), k.view(1, 1, 1, -1))
+    a = F.conv2d(F.pad(a, (0, 0, r, r), mode="reflect"), k.view(1, 1, -1, 1))
+    a = a[0, 0]
+    a = a - a.min()
+    a = a / a.max()
+    frames = torch.empty((n_frames, h, w), dtype=torch.float64, device=device)
+    frames[0] = a
+    for f in range(1, n_frames):
+        a = ((1 - fy) * ((1 - fx) * a[y0][:, x0] + fx * a[y0][:, x1]) +
+             fy * ((1 - fx) * a[y1][:, x0] + fx * a[y1][:, x1]))
+        frames[f] = a
+    return frames
+

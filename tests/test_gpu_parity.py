@@ -475,3 +475,17 @@ def test_planes_larger_than_4GiB(gpu_ctx, lkflow, torch):
     assert torch.isfinite(U).all().item() and torch.isfinite(V).all().item()
     lo, hi = U[0, :64], U[0, -64:]                                   # both ends of the plane were written
     assert lo.abs().max().item() > 0 and hi.abs().max().item() > 0
+
+
+def test_video_batch_shares_pyramids_bitwise(gpu_ctx, torch):
+    """Consecutive pairs of one frame buffer (next == prev + one frame) build each interior frame's pyramid once;
+    results must be bit-identical to the same pairs passed as unrelated buffers."""
+    import synth
+    frames = dev(torch, synth.video(6, 96, 160, seed=21))
+    Uv, Vv = gpu_ctx.compute_video(frames, 4, 7)                                   # shared-pyramid path
+    Ui, Vi = gpu_ctx.compute_batch(frames[:-1].clone(), frames[1:].clone(), 4, 7)  # independent buffers
+    assert torch.equal(Uv, Ui) and torch.equal(Vv, Vi)
+    strided = torch.zeros((6, 96, 200), dtype=torch.float64, device="cuda")       # padded rows, same video layout
+    strided[:, :, :160] = frames
+    Us, Vs = gpu_ctx.compute_video(strided[:, :, :160], 4, 7)
+    assert torch.equal(Us, Ui) and torch.equal(Vs, Vi)
