@@ -70,8 +70,10 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
     constexpr int R = WIN / 2;
     constexpr int XO = TX - 2 * R;            // output columns per block
     constexpr int PP = 16, PQ = 8;            // LDS pads (only non-output threads read them)
-    __shared__ double s_p[2][5][TX + 2 * PP];
-    __shared__ double s_q[2][5][TX / 2 + 2 * PQ];
+    // WIN == 3 in single-wave blocks: the whole horizontal window is reachable by DPP (62 of 64 lanes produce output)
+    constexpr bool DPP_ONLY = (WIN == 3 && TX == 64);
+    __shared__ double s_p[DPP_ONLY ? 1 : 2][DPP_ONLY ? 1 : 5][DPP_ONLY ? 1 : TX + 2 * PP];
+    __shared__ double s_q[DPP_ONLY ? 1 : 2][DPP_ONLY ? 1 : 5][DPP_ONLY ? 1 : TX / 2 + 2 * PQ];
 
     const int t = threadIdx.x;
     const int pair = blockIdx.z;
@@ -85,7 +87,13 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
     const int xl = r101(xc - 1, W);
     // buffer descriptors based at the first row the tile can touch (so that 32-bit offsets suffice for
     // any plane size); per-thread byte offsets of the own column and of the left derivative tap
-    const int row_lo = (H <= R + 1) ? 0 : max(y0 - R - 1, 0);
+    // Prefetch distance in marched rows.  A row of a small window is short (w3: ~0.25 us of work), so one row
+    // of lookahead does not cover the HBM latency: keep PF rows of image taps (and of coarse taps) in flight.
+    // PF must divide WIN so that queue slots are static in the unrolled chunk.  Big windows: 1 (registers).
+    constexpr int PF = (WIN == 3) ? 3 : 1;
+    static_assert(WIN % PF == 0, "queue slots are indexed by the static chunk position");
+    // rows the strip can touch: [y0-R-1, y1-1+R+PF] reflected once into the image (tiny images: anywhere)
+    const int row_lo = (H <= R + PF) ? 0 : max(y0 - R - PF, 0);
     const long long img_bytes = ((long long)(H - 1 - row_lo) * pitch + W) * 8;
     const __amdgpu_buffer_rsrc_t rI1 = buf_rsrc(a.i1.at(pair) + (long long)row_lo * pitch, img_bytes);
     const __amdgpu_buffer_rsrc_t rI2 = buf_rsrc(a.i2.at(pair) + (long long)row_lo * pitch, img_bytes);
@@ -108,11 +116,27 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         for (int f = 0; f < 5; ++f) ring[q][f] = 0.0;
     double pre[5] = {0, 0, 0, 0, 0};
 
-    // previous row (pa*, pb*) and prefetched current row (ca*, cb*): [0] = left tap, [1] = own
+    // byte offset of image row yy (reflected into the image; apron rows carry the reflect-101 row, so that at
+    // yy = 0 the "previous" row is row 1 = r101(-1); one reflection suffices unless the image is shorter than
+    // the apron)
+    auto img_row_off = [&](int yy) {
+        int rr = yy < 0 ? -yy : yy;
+        rr = rr >= H ? 2 * H - 2 - rr : rr;
+        if (H <= R + PF) rr = r101(yy, H);
+        return (rr - row_lo) * pitchb;
+    };
+    // previous row (pa*, pb*), current row (ca*, cb*) and the queue of rows in flight: [0] = left tap, [1] = own
     int ro = (r101(yy0 - 1, H) - row_lo) * pitchb;
     double pa0 = buf_ld(rI1, vxl, ro), pa1 = buf_ld(rI1, vxc, ro), pb0 = buf_ld(rI2, vxl, ro), pb1 = buf_ld(rI2, vxc, ro);
     ro = (r101(yy0, H) - row_lo) * pitchb;
     double ca0 = buf_ld(rI1, vxl, ro), ca1 = buf_ld(rI1, vxc, ro), cb0 = buf_ld(rI2, vxl, ro), cb1 = buf_ld(rI2, vxc, ro);
+    double qa0[PF], qa1[PF], qb0[PF], qb1[PF];                  // slot of marched row i = i % PF
+#pragma unroll
+    for (int r = 1; r < PF; ++r) {
+        const int o = img_row_off(yy0 + r);
+        qa0[r] = buf_ld(rI1, vxl, o); qa1[r] = buf_ld(rI1, vxc, o); qb0[r] = buf_ld(rI2, vxl, o); qb1[r] = buf_ld(rI2, vxc, o);
+    }
+    qa0[0] = qa1[0] = qb0[0] = qb1[0] = 0.0;
 
     [[maybe_unused]] UpSel1 us{};
     [[maybe_unused]] double hu[3] = {0, 0, 0}, hv[3] = {0, 0, 0};   // carried coarse rows s(i-1),s(i),s(i+1)
@@ -135,6 +159,21 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
             hv[s] = pyrup_h1v(buf_ld(rCV, us.jm, sr * cpvb), buf_ld(rCV, us.jc, sr * cpvb), buf_ld(rCV, us.jp, sr * cpvb), us);
         }
     }
+    // coarse taps of the "+= pyrUp" term, queued like the image rows: slot of marched row i = i % PF;
+    // windows divisible by 3 use the 3-taps-per-row scheme (see the row body) with a 3-slot queue
+    constexpr bool TAP3 = HAS_UP && (WIN % 3 == 0);
+    constexpr int LA = PF > 1 ? 1 : 0;                          // TAP3 lookahead in rows (the first output row is >= 2 rows in)
+    [[maybe_unused]] double tq3[3][3];
+    [[maybe_unused]] double tq[PF][6];
+    auto tap_row = [&](int y) { return max(up_srow(((y + 1) >> 1) + 1) - crow_lo, 0); };   // apron rows: clamped, unused
+    if (HAS_UP && !TAP3) {
+#pragma unroll
+        for (int r = 0; r < PF - 1; ++r) {
+            const int sr = tap_row(yy0 - R + r);
+            tq[r][0] = buf_ld(rCU, us.jm, sr * cpub); tq[r][1] = buf_ld(rCU, us.jc, sr * cpub); tq[r][2] = buf_ld(rCU, us.jp, sr * cpub);
+            tq[r][3] = buf_ld(rCV, us.jm, sr * cpvb); tq[r][4] = buf_ld(rCV, us.jc, sr * cpvb); tq[r][5] = buf_ld(rCV, us.jp, sr * cpvb);
+        }
+    }
     // outputs: descriptor based at the tile's first output row
     const int upb = (int)a.u.pitch * 8, vpb = (int)a.v.pitch * 8;
     const __amdgpu_buffer_rsrc_t rU = buf_rsrc(a.u.at(pair) + (long long)y0 * a.u.pitch, ((long long)(y1 - 1 - y0) * a.u.pitch + W) * 8);
@@ -155,16 +194,13 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         const int bsel = i & 1;
         const int yy = yy0 + i;
         const bool row_in = yy >= 0 && yy < H;
-        // prefetch the next image row (clamped, unconditional); consumed by the rotate below, after
-        // the window sums, so that its latency hides behind this row's work
-        // apron rows carry the reflected row (at yy = 0 the "previous" row is row 1 = r101(-1));
-        // one reflection suffices unless the image is shorter than the apron
-        int rr = yy + 1;
-        rr = rr < 0 ? -rr : rr;
-        rr = rr >= H ? 2 * H - 2 - rr : rr;
-        if (H <= R + 1) rr = r101(yy + 1, H);
-        const int rn = (rr - row_lo) * pitchb;
-        const double na0 = buf_ld(rI1, vxl, rn), na1 = buf_ld(rI1, vxc, rn), nb0 = buf_ld(rI2, vxl, rn), nb1 = buf_ld(rI2, vxc, rn);
+        // prefetch image row yy + PF into the queue slot that the rotate of the previous iteration freed
+        // (unconditional; consumed by a rotate PF iterations later, so its latency hides behind PF rows of work)
+        {
+            const int rn = img_row_off(yy + PF);
+            qa0[K % PF] = buf_ld(rI1, vxl, rn); qa1[K % PF] = buf_ld(rI1, vxc, rn);
+            qb0[K % PF] = buf_ld(rI2, vxl, rn); qb1[K % PF] = buf_ld(rI2, vxc, rn);
+        }
         const int y = yy - R;                                   // output row of this iteration
         const bool out_row = i >= 2 * R;
         // the NEXT coarse row of the "+= pyrUp" term is turned into the new carried slot in the epilogue of
@@ -172,12 +208,23 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         // row, unconditionally: with a conditional fetch the compiler's s_waitcnt before the products
         // (which only need the row prefetched one iteration ago) counts the minimum over both paths and
         // ends up waiting for the image loads issued just above on every odd row.
-        [[maybe_unused]] double uA = 0, uB = 0, uC = 0, vA = 0, vB = 0, vC = 0;
-        if (HAS_UP) {
-            const int sr = max(up_srow(((y + 1) >> 1) + 1) - crow_lo, 0);   // apron rows: clamped, value unused
+        if constexpr (TAP3) {
+            // three taps per row instead of six: the taps are consumed only in the epilogue of ODD output rows, so an
+            // even row fetches the u-plane taps and the odd row after it the v-plane taps of the same coarse row;
+            // plane descriptor and row offset are selected with scalar ops (the row parity is wave-uniform), the
+            // loads stay unconditional.  Slot of output row yq = its chunk position % 3.
+            const int yq = y + LA;
+            const bool odd = (yq & 1) != 0;
+            const __amdgpu_buffer_rsrc_t rs = odd ? rCV : rCU;
+            const int so = tap_row(yq | 1) * (odd ? cpvb : cpub);
+            constexpr int ts = (K + LA) % 3;
+            tq3[ts][0] = buf_ld(rs, us.jm, so); tq3[ts][1] = buf_ld(rs, us.jc, so); tq3[ts][2] = buf_ld(rs, us.jp, so);
+        } else if (HAS_UP) {                                    // taps of output row y + PF - 1 -> slot (K + PF - 1) % PF
+            constexpr int ts = (K + PF - 1) % PF;
+            const int sr = tap_row(y + PF - 1);
             const int su = sr * cpub, sv = sr * cpvb;
-            uA = buf_ld(rCU, us.jm, su); uB = buf_ld(rCU, us.jc, su); uC = buf_ld(rCU, us.jp, su);
-            vA = buf_ld(rCV, us.jm, sv); vB = buf_ld(rCV, us.jc, sv); vC = buf_ld(rCV, us.jp, sv);
+            tq[ts][0] = buf_ld(rCU, us.jm, su); tq[ts][1] = buf_ld(rCU, us.jc, su); tq[ts][2] = buf_ld(rCU, us.jp, su);
+            tq[ts][3] = buf_ld(rCV, us.jm, sv); tq[ts][4] = buf_ld(rCV, us.jc, sv); tq[ts][5] = buf_ld(rCV, us.jp, sv);
         }
         double p[5];
         {
@@ -191,23 +238,31 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
             p[0] = fx * fx; p[1] = fy * fy; p[2] = fx * fy; p[3] = fx * ft; p[4] = fy * ft;
         }
         LK3_STAMP(t1);
+        if constexpr (!DPP_ONLY) {
 #pragma unroll
-        for (int f = 0; f < 5; ++f) {
-            const double q = p[f] + dpp_swap1(p[f]);
-            s_p[bsel][f][PP + t] = p[f];
-            s_q[bsel][f][PQ + (t >> 1)] = q;                    // both lanes of a pair store the same value
+            for (int f = 0; f < 5; ++f) {
+                const double q = p[f] + dpp_swap1(p[f]);
+                s_p[bsel][f][PP + t] = p[f];
+                s_q[bsel][f][PQ + (t >> 1)] = q;                // both lanes of a pair store the same value
+            }
+            LK3_STAMP(t2);
+            __syncthreads();
+            LK3_STAMP(t3);
         }
-        LK3_STAMP(t2);
-        __syncthreads();
-        LK3_STAMP(t3);
 
         double S[5];
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
-            const double *q = &s_q[bsel][f][PQ + jb];
-            double h = s_p[bsel][f][PP + sidx];
+            double h;
+            if constexpr (DPP_ONLY) {
+                // 3-tap window inside one wave: both neighbours by DPP wave shifts, no LDS, no barrier
+                h = (dpp_wave_shr1(p[f]) + p[f]) + dpp_wave_shl1(p[f]);
+            } else {
+                const double *q = &s_q[bsel][f][PQ + jb];
+                h = s_p[bsel][f][PP + sidx];
 #pragma unroll
-            for (int j = 0; j < R; ++j) h += q[j];
+                for (int j = 0; j < R; ++j) h += q[j];
+            }
             // vertical van Herk / Gil-Werman step at static chunk position K
             pre[f] = (K == 0) ? h : pre[f] + h;
             S[f] = (K < WIN - 1) ? ring[(K + 1) % WIN][f] + pre[f] : pre[f];
@@ -223,7 +278,7 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         LK3_STAMP(t4);
         // rotate: the only wait for the prefetch
         pa0 = ca0; pa1 = ca1; pb0 = cb0; pb1 = cb1;
-        ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
+        ca0 = qa0[(K + 1) % PF]; ca1 = qa1[(K + 1) % PF]; cb0 = qb0[(K + 1) % PF]; cb1 = qb1[(K + 1) % PF];
 #ifdef LK3_STAMPS
         asm volatile("" :: "v"(pa0), "v"(ca0), "v"(ca1), "v"(cb0), "v"(cb1));
 #endif
@@ -256,8 +311,13 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
                 if (y & 1) {
                     u += ((hu[1] + hu[2]) * 4) * (1.0 / 64);
                     v += ((hv[1] + hv[2]) * 4) * (1.0 / 64);
-                    hu[0] = pyrup_h1v(uA, uB, uC, us);          // next coarse row, used from row y+1 on
-                    hv[0] = pyrup_h1v(vA, vB, vC, us);
+                    if constexpr (TAP3) {                       // u taps came with the previous (even) row, v taps with this one
+                        hu[0] = pyrup_h1v(tq3[(K + 2) % 3][0], tq3[(K + 2) % 3][1], tq3[(K + 2) % 3][2], us);
+                        hv[0] = pyrup_h1v(tq3[K % 3][0], tq3[K % 3][1], tq3[K % 3][2], us);
+                    } else {
+                        hu[0] = pyrup_h1v(tq[K % PF][0], tq[K % PF][1], tq[K % PF][2], us);   // next coarse row, used from row y+1 on
+                        hv[0] = pyrup_h1v(tq[K % PF][3], tq[K % PF][4], tq[K % PF][5], us);
+                    }
                 } else {
                     u += (hu[0] + hu[1] * 6 + hu[2]) * (1.0 / 64);
                     v += (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);

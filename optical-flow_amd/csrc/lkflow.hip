@@ -294,7 +294,10 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
         bool use128 = win <= 15 && c128 * 100 <= c256 * 108;
         { static const int e = getenv("LKFLOW_LK_TX") ? atoi(getenv("LKFLOW_LK_TX")) : 0;   // debug knob
           if (e == 128) use128 = true; else if (e == 256) use128 = false; }
-        int rc = use128 ? launch_lk3<128>(ctx, a, has_up, pairs, win, s) : launch_lk3<256>(ctx, a, has_up, pairs, win, s);
+        int rc;
+        static const bool no_w3 = getenv("LKFLOW_NO_W3_DPP") != nullptr;          // debug knob (A/B)
+        if (win == 3 && !no_w3) rc = launch_lk3_win<3, 64>(ctx, a, has_up, pairs, s);   // barrier-free DPP kernel
+        else rc = use128 ? launch_lk3<128>(ctx, a, has_up, pairs, win, s) : launch_lk3<256>(ctx, a, has_up, pairs, win, s);
 #endif
         if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
