@@ -180,6 +180,13 @@ __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int
     const lk_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return __hiloint2double((int)v.y, (int)v.x);
 }
+__device__ __forceinline__ void buf_st_cached(__amdgpu_buffer_rsrc_t r, int voff, int soff, double d)   // re-read soon
+{
+    lk_u2 v;
+    v.x = (unsigned)__double2loint(d);
+    v.y = (unsigned)__double2hiint(d);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, int voff, int soff, double d)
 {
     lk_u2 v;

@@ -47,7 +47,6 @@ struct PyrDownArgs {
     int H, W, Hd, Wd;
     int gx, gy;        // tiles per plane
     int th;            // output rows per block
-    int vec_src;       // src: 16-byte aligned base, even pitch/plane -> double2 loads
 };
 
 constexpr int PD_WCOLS = 62;                          // valid output columns per wave
@@ -81,17 +80,25 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
     const double *s = a.src.at(plane);
     const int pitch = (int)a.src.pitch;
     const int c0 = 2 * ox;                                  // source columns c0, c0+1
-    const bool vec = a.vec_src && c0 >= 0 && c0 + 1 < W;
+    // wave-uniform: only the first / last wave of a row has lanes outside the image (a per-lane condition would
+    // make the compiler select between two addresses and issue two 8-byte loads per row for every lane)
+    const bool vec = __all(c0 >= 0 && c0 + 1 < W);
     const int r0c = r101(c0, W), r1c = r101(c0 + 1, W);
+    // source rows through a buffer descriptor based at the strip's first row (scalar row offset, 4-byte
+    // alignment suffices for the 16-byte access, 32-bit offsets for any plane size)
+    const int row_lo = H < 4 ? 0 : max(2 * oy0 - 2, 0);
+    const __amdgpu_buffer_rsrc_t rS = buf_rsrc(s + (long long)row_lo * pitch, ((long long)(H - 1 - row_lo) * pitch + W) * 8);
+    const int pitchb = pitch * 8;
 
     // one source row: 16-byte load of this lane's column pair (issued early) ...
     auto ld = [&](int sy, double &cx, double &cy) __attribute__((always_inline)) {
-        const double *r = s + r101(sy, H) * pitch;          // row index is wave-uniform
+        const int so = (r101(sy, H) - row_lo) * pitchb;     // row index is wave-uniform
         if (vec) {
-            const double2 p = *reinterpret_cast<const double2 *>(r + c0);
-            cx = p.x; cy = p.y;
+            typedef unsigned int lk_u4 __attribute__((ext_vector_type(4)));
+            const lk_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rS, c0 * 8, so, 0);
+            cx = __hiloint2double((int)v.y, (int)v.x); cy = __hiloint2double((int)v.w, (int)v.z);
         } else {
-            cx = r[r0c]; cy = r[r1c];
+            cx = buf_ld(rS, r0c * 8, so); cy = buf_ld(rS, r1c * 8, so);
         }
     };
     // ... and its horizontal result for this lane's output column (neighbour taps by DPP wave shifts)
@@ -104,8 +111,10 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
     ld(2 * oy0 - 2, ax, ay); ld(2 * oy0 - 1, bx2, by2); ld(2 * oy0, cx2, cy2);
     double h0 = hf(ax, ay), h1 = hf(bx2, by2), h2 = hf(cx2, cy2);
     const bool out_lane = lane >= 1 && lane <= PD_WCOLS && ox < a.Wd;
-    const int dp = (int)a.dst.pitch;
-    double *d = a.dst.at(plane) + oy0 * dp + ox;
+    const int dpb = (int)a.dst.pitch * 8, ox8 = ox * 8;
+    const __amdgpu_buffer_rsrc_t rD = buf_rsrc(a.dst.at(plane) + (long long)oy0 * a.dst.pitch,
+                                               ((long long)(oy1 - 1 - oy0) * a.dst.pitch + a.Wd) * 8);
+    int so = 0;                                             // byte offset of output row oy inside the strip
     // two output rows per iteration: four independent 16-byte loads in flight per lane
     int oy = oy0;
     for (; oy + 1 < oy1; oy += 2) {
@@ -114,15 +123,15 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
         const double h3 = hf(p3x, p3y), h4 = hf(p4x, p4y), h5 = hf(p5x, p5y), h6 = hf(p6x, p6y);
         const double o0 = (h2 * 6 + (h1 + h3) * 4 + h0 + h4) * (1.0 / 256);
         const double o1 = (h4 * 6 + (h3 + h5) * 4 + h2 + h6) * (1.0 / 256);
-        if (out_lane) { d[0] = o0; d[dp] = o1; }          // (cached: the next level and LK re-read it soon)
-        d += 2 * dp;
+        if (out_lane) { buf_st_cached(rD, ox8, so, o0); buf_st_cached(rD, ox8, so + dpb, o1); }   // next level / LK re-read it soon
+        so += 2 * dpb;
         h0 = h4; h1 = h5; h2 = h6;
     }
     if (oy < oy1) {
         double p3x, p3y, p4x, p4y;
         ld(2 * oy + 1, p3x, p3y); ld(2 * oy + 2, p4x, p4y);
         const double h3 = hf(p3x, p3y), h4 = hf(p4x, p4y);
-        if (out_lane) d[0] = (h2 * 6 + (h1 + h3) * 4 + h0 + h4) * (1.0 / 256);
+        if (out_lane) buf_st_cached(rD, ox8, so, (h2 * 6 + (h1 + h3) * 4 + h0 + h4) * (1.0 / 256));
     }
 }
 

@@ -306,11 +306,6 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
     return LKFLOW_E_ARG;
 }
 
-inline bool vec16(const void *p, long long plane, long long pitch)
-{
-    return ((uintptr_t)p % 16 == 0) && (plane % 2 == 0) && (pitch % 2 == 0);
-}
-
 int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int planes, hipStream_t s)
 {
     lk::PyrDownArgs a{};
@@ -322,7 +317,7 @@ int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int p
     a.th = LK_PD_TH;
     { static const int e = getenv("LKFLOW_PD_TH") ? atoi(getenv("LKFLOW_PD_TH")) : 0; if (e > 0) a.th = e; }
     a.gx = (a.Wd + 4 * lk::PD_WCOLS - 1) / (4 * lk::PD_WCOLS); a.gy = (a.Hd + a.th - 1) / a.th;
-    a.vec_src = vec16(src.base, src.plane, src.pitch);
+    if ((long long)(2 * a.th + 6) * 8 * std::max(src.pitch, dst.pitch) > 0x7fffffffLL) return LKFLOW_E_ARG;   // strip-relative 32-bit offsets
     const long long n = (long long)a.gx * a.gy * planes;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
     hipLaunchKernelGGL(lk::pyrdown_kernel, dim3((unsigned)n), dim3(256), 0, s, a);
