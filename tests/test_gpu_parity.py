@@ -489,3 +489,24 @@ def test_video_batch_shares_pyramids_bitwise(gpu_ctx, torch):
     strided[:, :, :160] = frames
     Us, Vs = gpu_ctx.compute_video(strided[:, :, :160], 4, 7)
     assert torch.equal(Us, Ui) and torch.equal(Vs, Vi)
+
+
+def test_random_small_shapes_against_oracle(gpu_ctx, oracle, lkflow, torch):
+    """Ragged inputs: 60 seeded random (rows, cols, levels, window) combinations, most of them smaller than the
+    window / the block / the prefetch depth, pyramid and single-level paths, batched in pairs of different content."""
+    rng = np.random.default_rng(2026)
+    wins = [3, 3, 5, 7, 9, 15, 21, 27, 31]
+    for it in range(60):
+        lv_target = int(rng.integers(1, 5))
+        h = int(rng.integers(1, 40)) << (lv_target - 1)
+        w = int(rng.integers(1, 40)) << (lv_target - 1)
+        levels = min(lv_target, lkflow.max_levels(w, h))
+        win = wins[int(rng.integers(0, len(wins)))]
+        a = rng.random((2, h, w)); b = rng.random((2, h, w))
+        a[1, : h // 2] = 0.25; b[1, : h // 2] = 0.25                      # a flat half: det == 0 -> flow exactly 0
+        U, V = gpu_ctx.compute_batch(dev(torch, a), dev(torch, b), levels, win)
+        U, V = host(U), host(V)
+        for p in range(2):
+            uo, vo = oracle.coarse_to_fine(a[p], b[p], levels, win)
+            scale = np.maximum(1.0, np.maximum(np.abs(uo), np.abs(vo)))
+            assert (np.abs(U[p] - uo) / scale).max() <= TOL and (np.abs(V[p] - vo) / scale).max() <= TOL, (it, h, w, levels, win)
