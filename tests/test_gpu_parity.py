@@ -500,7 +500,7 @@ def test_random_small_shapes_against_oracle(gpu_ctx, oracle, lkflow, torch):
         lv_target = int(rng.integers(1, 5))
         h = int(rng.integers(1, 40)) << (lv_target - 1)
         w = int(rng.integers(1, 40)) << (lv_target - 1)
-        levels = min(lv_target, lkflow.max_levels(w, h))
+        levels = min(lv_target, lkflow.getMaxLayer(w, h))
         win = wins[int(rng.integers(0, len(wins)))]
         a = rng.random((2, h, w)); b = rng.random((2, h, w))
         a[1, : h // 2] = 0.25; b[1, : h // 2] = 0.25                      # a flat half: det == 0 -> flow exactly 0
