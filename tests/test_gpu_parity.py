@@ -510,3 +510,23 @@ def test_random_small_shapes_against_oracle(gpu_ctx, oracle, lkflow, torch):
             uo, vo = oracle.coarse_to_fine(a[p], b[p], levels, win)
             scale = np.maximum(1.0, np.maximum(np.abs(uo), np.abs(vo)))
             assert (np.abs(U[p] - uo) / scale).max() <= TOL and (np.abs(V[p] - vo) / scale).max() <= TOL, (it, h, w, levels, win)
+
+
+@pytest.mark.parametrize("win", [3, 15, 21])
+def test_block_boundary_widths_against_oracle(gpu_ctx, oracle, torch, win):
+    """Widths just below / at / above what one LK block (64, 128 or 256 lanes minus the 2R halo) and one pyrDown wave
+    (62 columns) cover, heights around the strip heights: every output column next to a block seam is checked."""
+    rng = np.random.default_rng(win)
+    R = win // 2
+    widths = sorted({64 - 2 * R + d for d in (-1, 0, 1)} | {128 - 2 * R + d for d in (-1, 0, 1)} |
+                    {256 - 2 * R + d for d in (-1, 0, 1)} | {2 * (128 - 2 * R) + d for d in (0, 1)} | {123, 124, 125, 248, 249})
+    for w in widths:
+        if w < 2:
+            continue
+        w2 = w + (w & 1)                                               # 2 levels need even sizes
+        for h, levels, ww in ((37, 1, w), (46, 2, w2)):
+            a, b = rng.random((1, h, ww)), rng.random((1, h, ww))
+            U, V = gpu_ctx.compute_batch(dev(torch, a), dev(torch, b), levels, win)
+            uo, vo = oracle.coarse_to_fine(a[0], b[0], levels, win)
+            scale = np.maximum(1.0, np.maximum(np.abs(uo), np.abs(vo)))
+            assert (np.abs(host(U)[0] - uo) / scale).max() <= TOL and (np.abs(host(V)[0] - vo) / scale).max() <= TOL, (w, h, levels)
