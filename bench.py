@@ -154,6 +154,21 @@ def video_pipeline_rate(lkf, torch, device, frames=50, side=1080, levels=4, win=
             "note": "rank 0 only, extra measurement after the timed region; includes the 3-scalar D2H copy"}
 
 
+def copy_ceiling(torch, device, nbytes=2 << 30, reps=10):
+    """Extra: the achievable-copy ceiling of this box: a device-to-device copy of 2 GiB, bytes read +
+    bytes written per second.  The 8 TB/s `roofline.peak` is the spec figure; this is what a plain copy reaches."""
+    a = torch.empty(nbytes // 8, dtype=torch.float64, device=f"cuda:{device}").normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3)
+
+
 def cpu_baseline(cols, rows, levels, win, budget_s=20.0):
     """Times oracle/lk_cpu_omp.c (the restated ParallelVideoPyr.cpp CPU path) on this host."""
     import synth
@@ -379,6 +394,12 @@ def main():
         if world == 1 and K == 1 and not args.graph and P >= 8 and not args.no_extras:
             out["pipelined"] = pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, local_rank, world)
         if world == 1 and not args.no_extras:
+            ceil_bps = copy_ceiling(torch, local_rank)
+            out["copy_ceiling"] = {"GBps": round(ceil_bps / 1e9, 1), "what": "2 GiB device-to-device copy, read + written bytes",
+                                   "lk0_algorithmic_frac": round(achieved / ceil_bps, 4),
+                                   "lk0_traffic_frac": (round(out["roofline"]["traffic"] / lk0_avg_s / ceil_bps, 4)
+                                                        if out["roofline"]["traffic"] else None),
+                                   "path_algorithmic_frac": round(path_achieved / ceil_bps, 4)}
             out["preprocess"] = preprocess_rate(ctx, torch, local_rank)
             out["video_pipeline"] = video_pipeline_rate(lkf, torch, local_rank)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:

@@ -16,3 +16,14 @@ def test_algorithmic_bytes_match_survey_figures():
     # dominant kernel (LK at level 0): read 2 images + coarse u,v, write u,v = 36 B/px
     assert bench.lk0_bytes_per_pair(1920, 1080, 3) == 36 * 1920 * 1080
     assert set(bench.CONFIGS) >= {"1080p", "4k", "8k", "pacman", "webcam"}
+
+
+def test_committed_pmc_traffic_is_usable_by_bench():
+    """roofline.traffic comes from profiles/pmc_traffic.json: the committed file must be tagged with the headline
+    workload and give a per-launch figure between the algorithmic bytes and twice that (aprons, halos)."""
+    import bench
+    cols, rows, levels, win, pairs = bench.CONFIGS["1080p"]
+    t = bench.measured_traffic(f"lk::lk_march3_kernel<{win}, ", cols, rows, pairs)
+    alg = bench.lk0_bytes_per_pair(cols, rows, levels) * pairs
+    assert t is not None and alg <= t <= 2 * alg
+    assert bench.measured_traffic(f"lk::lk_march3_kernel<{win}, ", cols, rows, pairs + 1) is None   # other workloads: null

@@ -48,5 +48,7 @@ for k in sorted(acc):
                 print(f"   -> {n}/wave = {c[n] / w:10.1f}")
 
 if len(sys.argv) > 2:
+    # bench.py only trusts the file for the workload it was collected on ("<cols>x<rows>x<pairs per launch>")
+    workload = sys.argv[3] if len(sys.argv) > 3 else "1920x1080x32"
     with open(sys.argv[2], "w") as fh:
-        json.dump(traffic, fh, indent=1)
+        json.dump({"_workload": workload, **traffic}, fh, indent=1)
