@@ -1,20 +1,21 @@
 // lk_march3.h -- single-level dense LK, row-marching kernel, one column per thread, lean body.
 //
-// Same stage semantics as lk_march_kernel (lk_kernels.h).  What bounds this kernel is fp64 VALU /
-// LDS instruction issue, so the body is organised for instruction count and for <= 256 VGPRs
-// (2 waves per SIMD):
-//   * thread t owns column x = x_base + t; per row: one 8-byte load per image + one for the left
-//     derivative tap (reflect-101 folded into the index), previous row carried in registers, next
-//     row prefetched;
+// What bounds this kernel is fp64 VALU / LDS / VMEM instruction issue at the occupancy the register
+// ring allows, so the body is organised for instruction count and for <= 256 VGPRs (2 waves per SIMD
+// up to WIN = 15):
+//   * thread t owns column x = x_base + t; per row: one 8-byte buffer load per image + one for the left
+//     derivative tap (reflect-101 folded into the index; scalar row offset, no vector address
+//     arithmetic), previous row carried in registers, PF rows prefetched (PF = 3 for WIN = 3, else 1);
 //   * horizontal WIN-tap sums: lanes 2j,2j+1 form the pair sum q_j = p(2j)+p(2j+1) with one DPP
 //     quad-permute (no LDS round trip); every lane stores p, even lanes store q; a window is then
 //     R pair sums + one single = R+1 LDS reads and R adds per field instead of WIN and WIN-1;
-//   * ONE barrier per marched row (double-buffered LDS rows);
+//     ONE barrier per marched row (double-buffered LDS rows).  WIN = 3 in single-wave blocks (TX = 64):
+//     the window is two DPP wave shifts -- no LDS, no barrier;
 //   * vertical WIN-tap sums: van Herk / Gil-Werman prefix + suffix ring in REGISTERS, statically
-//     indexed (dispatch on the wave-uniform chunk position); additions only -- no running
-//     subtract, so flat regions stay exactly 0 like the reference;
+//     indexed (the chunk of WIN rows is unrolled through a template fold); additions only -- no
+//     running subtract, so flat regions stay exactly 0 like the reference;
 //   * "+= pyrUp(coarse flow)": the horizontally filtered coarse rows are carried in registers and
-//     refreshed every second fine row.
+//     refreshed every second fine row; their taps are fetched 3 per row (WIN divisible by 3) or 6.
 #pragma once
 #include "lk_kernels.h"
 
@@ -85,14 +86,14 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
     const bool col_in = x >= 0 && x < W;
     const int xc = min(max(x, 0), W - 1);
     const int xl = r101(xc - 1, W);
-    // buffer descriptors based at the first row the tile can touch (so that 32-bit offsets suffice for
-    // any plane size); per-thread byte offsets of the own column and of the left derivative tap
     // Prefetch distance in marched rows.  A row of a small window is short (w3: ~0.25 us of work), so one row
     // of lookahead does not cover the HBM latency: keep PF rows of image taps (and of coarse taps) in flight.
     // PF must divide WIN so that queue slots are static in the unrolled chunk.  Big windows: 1 (registers).
     constexpr int PF = (WIN == 3) ? 3 : 1;
     static_assert(WIN % PF == 0, "queue slots are indexed by the static chunk position");
-    // rows the strip can touch: [y0-R-1, y1-1+R+PF] reflected once into the image (tiny images: anywhere)
+    // buffer descriptors based at the first row the strip can touch (so that 32-bit offsets suffice for any
+    // plane size): rows [y0-R-1, y1-1+R+PF] reflected once into the image (tiny images: anywhere); per-thread
+    // byte offsets of the own column and of the left derivative tap
     const int row_lo = (H <= R + PF) ? 0 : max(y0 - R - PF, 0);
     const long long img_bytes = ((long long)(H - 1 - row_lo) * pitch + W) * 8;
     const __amdgpu_buffer_rsrc_t rI1 = buf_rsrc(a.i1.at(pair) + (long long)row_lo * pitch, img_bytes);
