@@ -530,3 +530,25 @@ def test_block_boundary_widths_against_oracle(gpu_ctx, oracle, torch, win):
             uo, vo = oracle.coarse_to_fine(a[0], b[0], levels, win)
             scale = np.maximum(1.0, np.maximum(np.abs(uo), np.abs(vo)))
             assert (np.abs(host(U)[0] - uo) / scale).max() <= TOL and (np.abs(host(V)[0] - vo) / scale).max() <= TOL, (w, h, levels)
+
+
+def test_empty_and_null_inputs_are_rejected(gpu_ctx, lkflow, torch):
+    """Empty inputs (0 rows / 0 columns / 0 pairs) and null pointers return LKFLOW_E_ARG from every compute entry point
+    (the reference would dereference an empty Mat); nothing is launched and the context stays usable."""
+    L = lkflow.lib()
+    a = torch.zeros((1, 8, 8), dtype=torch.float64, device="cuda")
+    p, h = a.data_ptr(), gpu_ctx._h
+    E = lkflow.LKFLOW_E_ARG
+    for rows, cols, pairs in ((0, 8, 1), (8, 0, 1), (8, 8, 0), (-1, 8, 1)):
+        assert L.lkflow_compute_batch_f64_dev(h, p, p, 512, 512, pairs, rows, cols, 64, p, p, 512, 64, 1, 3, 0, None) == E
+        assert L.lkflow_lk_batch_f64_dev(h, p, p, 512, 512, pairs, rows, cols, 64, p, p, 512, 64, 3, None) == E
+        assert L.lkflow_pyrdown_f64_dev(h, p, 512, pairs, rows, cols, 64, p, 512, 64, None) == E
+        assert L.lkflow_flow_centroid_f64_dev(h, p, p, 512, pairs, rows, cols, 64, 20.0, p, None) == E
+        assert L.lkflow_edge_map_u8_dev(h, p, 64, pairs, rows, cols, 8, 10, p, 512, 64, None) == E
+        assert L.lkflow_blur_gray_bgr8_dev(h, p, 192, pairs, rows, cols, 24, 9, 1.5, p, 64, 8, None) == E
+    assert L.lkflow_compute_batch_f64_dev(h, None, p, 512, 512, 1, 8, 8, 64, p, p, 512, 64, 1, 3, 0, None) == E
+    assert L.lkflow_compute_batch_f64_dev(h, p, p, 512, 512, 1, 8, 8, 64, None, p, 512, 64, 1, 3, 0, None) == E
+    assert L.lkflow_compute_batch_f64_dev(None, p, p, 512, 512, 1, 8, 8, 64, p, p, 512, 64, 1, 3, 0, None) == E
+    assert L.lkflow_u8_to_f64_dev(h, p, p, 0, None) == lkflow.LKFLOW_OK          # n == 0: nothing to do
+    u, v = gpu_ctx.compute_batch(a, a.clone(), 1, 3)                              # still usable; flat input -> exactly 0
+    assert not u.any().item() and not v.any().item()
