@@ -169,6 +169,21 @@ def copy_ceiling(torch, device, nbytes=2 << 30, reps=10):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3)
 
 
+def host_call_rate(ctx, cols, rows, levels, win, reps=5):
+    """Extra: the host-buffer drop-in call (lkflow_compute_f64 = the cv::Mat entry point): pageable host arrays in,
+    host arrays out, synchronous -- i.e. the PCIe-inclusive rate of one pair.  Never `value`."""
+    import synth
+    a, b = synth.frame_pair(rows, cols, seed=99)
+    ctx.computeFlow(a, b, levels, win)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.computeFlow(a, b, levels, win)
+    dt = (time.perf_counter() - t0) / reps
+    return {"ms_per_pair": round(dt * 1e3, 3), "Mpixels_per_s": round(rows * cols / dt / 1e6, 1),
+            "bytes_over_pcie_per_pair": 4 * rows * cols * 8,
+            "note": "rank 0 only, extra: 2 planes H2D + 2 planes D2H from pageable memory around the same kernels"}
+
+
 def cpu_baseline(cols, rows, levels, win, budget_s=20.0):
     """Times oracle/lk_cpu_omp.c (the restated ParallelVideoPyr.cpp CPU path) on this host."""
     import synth
@@ -401,6 +416,7 @@ def main():
                                    "lk0_traffic_frac": (round(out["roofline"]["traffic"] / lk0_avg_s / ceil_bps, 4)
                                                         if out["roofline"]["traffic"] else None),
                                    "path_algorithmic_frac": round(path_achieved / ceil_bps, 4)}
+            out["host_buffer_call"] = host_call_rate(ctx, cols, rows, levels, win)
             out["preprocess"] = preprocess_rate(ctx, torch, local_rank)
             out["video_pipeline"] = video_pipeline_rate(lkf, torch, local_rank)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
