@@ -21,6 +21,7 @@
 #include "../../include/lkflow.h"
 #include "lk_kernels.h"
 #include "lk_march3.h"
+#include "lk_w3x2.h"
 
 #define LKFLOW_VERSION_STR "lkflow-mi355x 0.1 (gfx950)"
 
@@ -255,6 +256,32 @@ int launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStr
     return LKFLOW_OK;
 }
 
+// 3 x 3 windows on even-width levels: two columns per lane (lk_w3x2.h)
+int launch_w3x2(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
+{
+    static int bpc[2] = {0, 0};
+    if (bpc[has_up] == 0) {
+        int n = 0;
+        const hipError_t e = has_up ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lk::lk_w3x2_kernel<true>, 64, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lk::lk_w3x2_kernel<false>, 64, 0);
+        bpc[has_up] = (e == hipSuccess && n >= 1) ? n : 1;
+    }
+    const int gx = (a.W + lk::W3X2_XO - 1) / lk::W3X2_XO;
+    int th = ctx->tile_rows > 0 ? ctx->tile_rows : pick_tile_rows(a.H, 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc[has_up]);
+    if (th > a.H) th = a.H;
+    {
+        const long long pmax = std::max(a.i1.pitch, std::max(a.u.pitch, a.v.pitch));
+        const long long cap = 0x7fffffffLL / (pmax * 8) - 12;
+        if (cap < 1) return LKFLOW_E_ARG;
+        if (th > cap) th = (int)cap;
+    }
+    a.th = th;
+    dim3 grid(gx, (a.H + th - 1) / th, pairs);
+    if (has_up) hipLaunchKernelGGL(lk::lk_w3x2_kernel<true>, grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(lk::lk_w3x2_kernel<false>, grid, dim3(64), 0, s, a);
+    return LKFLOW_OK;
+}
+
 template <int TX>
 int launch_lk3(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, int win, hipStream_t s)
 {
@@ -296,7 +323,9 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
           if (e == 128) use128 = true; else if (e == 256) use128 = false; }
         int rc;
         static const bool no_w3 = getenv("LKFLOW_NO_W3_DPP") != nullptr;          // debug knob (A/B)
-        if (win == 3 && !no_w3) rc = launch_lk3_win<3, 64>(ctx, a, has_up, pairs, s);   // barrier-free DPP kernel
+        static const bool no_x2 = getenv("LKFLOW_NO_W3X2") != nullptr;            // debug knob (A/B)
+        if (win == 3 && !no_x2 && a.W >= 2 && !(a.W & 1)) rc = launch_w3x2(ctx, a, has_up, pairs, s);   // 2 columns per lane
+        else if (win == 3 && !no_w3) rc = launch_lk3_win<3, 64>(ctx, a, has_up, pairs, s);   // barrier-free DPP kernel
         else rc = use128 ? launch_lk3<128>(ctx, a, has_up, pairs, win, s) : launch_lk3<256>(ctx, a, has_up, pairs, win, s);
 #endif
         if (rc) return rc;
