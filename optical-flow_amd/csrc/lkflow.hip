@@ -22,6 +22,7 @@
 #include "lk_kernels.h"
 #include "lk_march3.h"
 #include "lk_w3x2.h"
+#include "lk_w3x2f.h"
 
 #define LKFLOW_VERSION_STR "lkflow-mi355x 0.1 (gfx950)"
 
@@ -279,6 +280,34 @@ int launch_w3x2(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream
     dim3 grid(gx, (a.H + th - 1) / th, pairs);
     if (has_up) hipLaunchKernelGGL(lk::lk_w3x2_kernel<true>, grid, dim3(64), 0, s, a);
     else hipLaunchKernelGGL(lk::lk_w3x2_kernel<false>, grid, dim3(64), 0, s, a);
+    return LKFLOW_OK;
+}
+
+// warp + LK fused for 3 x 3 windows (lk_w3x2f.h): a.i1 / a.i2 are the UN-warped level images
+bool fused_w3_applies(const lkflow_ctx *ctx, int win, int W, int H)
+{
+    static const bool off = getenv("LKFLOW_NO_W3_FUSED") != nullptr || getenv("LKFLOW_NO_W3X2") != nullptr;   // debug knobs (A/B)
+    return !off && ctx->impl == 0 && win == 3 && W >= 2 && !(W & 1) && !(H & 1);
+}
+int launch_w3x2f(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
+{
+    static int bpc = 0;
+    if (bpc == 0) {
+        int n = 0;
+        bpc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lk::lk_w3x2f_kernel, 64, 0) == hipSuccess && n >= 1) ? n : 1;
+    }
+    const int gx = (a.W + lk::W3X2_XO - 1) / lk::W3X2_XO;
+    int th = ctx->tile_rows > 0 ? ctx->tile_rows : pick_tile_rows(a.H, 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
+    if (th > a.H) th = a.H;
+    {
+        const long long pmax = std::max(std::max(a.cu.pitch, a.cv.pitch), std::max(a.u.pitch, a.v.pitch));
+        const long long cap = 0x7fffffffLL / (pmax * 8) - 12;
+        if (cap < 1) return LKFLOW_E_ARG;
+        if (th > cap) th = (int)cap;
+    }
+    a.th = th;
+    hipLaunchKernelGGL(lk::lk_w3x2f_kernel, dim3(gx, (a.H + th - 1) / th, pairs), dim3(64), 0, s, a);
+    HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }
 
@@ -592,6 +621,14 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
         a.H = lv[l].H; a.W = lv[l].W;
         a.u = flow_w(l, 0); a.v = flow_w(l, 1);
         const bool has_up = l != L - 1;
+        if (has_up && fused_w3_applies(ctx, win, lv[l].W, lv[l].H) && !((flags & LKFLOW_MUTATE_INPUTS) && l == 0)) {
+            // 3 x 3: warp and LK in one kernel, the warped images never reach memory (lk_w3x2f.h)
+            a.i1 = pyr(l, 0); a.i2 = pyr(l, 1);
+            a.cu = as_c(flow_w(l + 1, 0)); a.cv = as_c(flow_w(l + 1, 1));
+            ProfScope ps(ctx, LKFLOW_STAGE_LK, l, s);
+            if ((rc = launch_w3x2f(ctx, a, P, s))) return rc;
+            continue;
+        }
         if (has_up) {
             CPlanes cu = as_c(flow_w(l + 1, 0)), cv = as_c(flow_w(l + 1, 1));
             // a9-a12: warp level l with the up-sampled flow of level l+1
