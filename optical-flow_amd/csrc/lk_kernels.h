@@ -6,6 +6,7 @@
 //   warp_kernel           a9+a10+a11  pyrUp(flow) -> float map -> fixed-point bilinear remap (1x4 strips)
 //   lk_march3_kernel<WIN> a3..a8  derivatives, products, win x win sums, 2x2 solve, += pyrUp(flow)  (lk_march3.h)
 //   lk_w3x2_kernel        a3..a8  3 x 3 windows, two columns per lane, no LDS  (lk_w3x2.h)
+//   lk_w3x2f_kernel       a9..a12 + a3..a8  3 x 3 windows: warp fused into the LK kernel  (lk_w3x2f.h)
 //   lk_naive_kernel       a3..a8  per-pixel restatement (cross-check only)
 //   blur_gray_kernel      f2   GaussianBlur(k x k, sigma) on 8UC3 + BGR2GRAY (OpenCV 2.4 fixed point)
 //   frame_diff_kernel     f2   cur - rate*prev on 8UC1 (addWeighted float arithmetic)
