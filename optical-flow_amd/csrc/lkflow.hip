@@ -16,11 +16,13 @@
 #include <cstdint>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/lkflow.h"
 #include "lk_kernels.h"
 #include "lk_march3.h"
+#include "lk_split.h"
 #include "lk_w3x2.h"
 #include "lk_w3x2f.h"
 
@@ -63,6 +65,8 @@ struct lkflow_ctx {
     std::vector<long long> off_pyr;   // level >= 1
     std::vector<long long> off_warp;  // level <= L-2
     std::vector<long long> off_flow;  // level >= 1: u planes [pairs] then v planes [pairs]
+    // resident blocks per CU of each kernel instantiation ON THIS DEVICE (occupancy query, first use)
+    std::unordered_map<const void *, int> occ;
     // host-API staging (prev, next, U, V contiguous planes)
     double *stage = nullptr;
     size_t stage_bytes = 0;
@@ -179,19 +183,18 @@ inline dim3 grid_px(int W, int H, int planes) { return dim3((W + 63) / 64, (H + 
 
 // ---- LK launch ---------------------------------------------------------------------------------
 
-// Resident blocks per CU of one LK instantiation (occupancy query, cached per process).
-template <int WIN, int TX, bool HAS_UP>
-int lk3_blocks_per_cu()
+// Resident blocks per CU of one kernel instantiation on the context's device (occupancy query, cached in the
+// context: contexts are per device and per caller thread, so there is no shared mutable state).
+template <typename Kern>
+int blocks_per_cu(lkflow_ctx *ctx, Kern kern, int threads)
 {
-    static int cached = 0;
-    if (cached == 0) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lk::lk_march3_kernel<WIN, TX, HAS_UP>, TX, 0) !=
-                hipSuccess || n < 1)
-            n = 1;
-        cached = n;
-    }
-    return cached;
+    const void *key = reinterpret_cast<const void *>(kern);
+    auto it = ctx->occ.find(key);
+    if (it != ctx->occ.end()) return it->second;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, 0) != hipSuccess || n < 1) n = 1;
+    ctx->occ.emplace(key, n);
+    return n;
 }
 
 // Rows per block: every block marches th + 2R rows and blocks run in rounds of `slots` resident
@@ -219,7 +222,8 @@ int launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStr
     const int gx = (a.W + xo - 1) / xo;
     int th = ctx->tile_rows;
     if (th <= 0) {
-        const int bpc = has_up ? lk3_blocks_per_cu<WIN, TX, true>() : lk3_blocks_per_cu<WIN, TX, false>();
+        const int bpc = has_up ? blocks_per_cu(ctx, lk::lk_march3_kernel<WIN, TX, true>, TX)
+                               : blocks_per_cu(ctx, lk::lk_march3_kernel<WIN, TX, false>, TX);
         th = pick_tile_rows(a.H, R, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
     }
     if (th > a.H) th = a.H;
@@ -257,18 +261,75 @@ int launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStr
     return LKFLOW_OK;
 }
 
+// Wave-specialised kernel (lk_split.h): K*64-column blocks, K PE waves + 5 window-sum waves
+template <int WIN, int K>
+int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
+{
+    using C = lk::SplitCfg<WIN, K>;
+    if ((a.W & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return -1;   // odd / tiny levels: one-role kernel
+    const int gx = (a.W + C::XO - 1) / C::XO;
+    int th = ctx->tile_rows;
+    if (th <= 0) {
+        const int bpc = has_up ? blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, true>, C::NT)
+                               : blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, false>, C::NT);
+        th = pick_tile_rows(a.H, C::R + 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
+    }
+    th = (th + 1) & ~1;                              // even strips: row parity is static in the unrolled pipeline
+    {
+        const long long pmax = std::max(a.i1.pitch, std::max(a.u.pitch, a.v.pitch));
+        const long long cap = (0x7fffffffLL / (pmax * 8) - 2 * C::R - 8) & ~1LL;
+        if (cap < 2) return LKFLOW_E_ARG;
+        if (th > cap) th = (int)cap;
+    }
+    a.th = th;
+    dim3 grid(gx, (a.H + th - 1) / th, pairs);
+#ifdef LK_SPLIT_STAMPS
+    {   // diagnostic build: dump the stamps of the largest launch to $LKFLOW_STAMPS_OUT after the run
+        static unsigned long long *dbuf = nullptr; static size_t dn = 0;
+        const size_t nw = (size_t)grid.x * grid.y * grid.z * C::NW;
+        if (has_up && nw * 8 > dn) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc((void **)&dbuf, nw * 64); dn = nw * 8; }
+        a.dbg = (has_up && nw * 8 == dn) ? dbuf : nullptr;
+        if (a.dbg && getenv("LKFLOW_STAMPS_OUT")) {
+            hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true>), grid, dim3(C::NT), 0, s, a);
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h(dn);
+            (void)hipMemcpy(h.data(), dbuf, dn * 8, hipMemcpyDeviceToHost);
+            FILE *f = fopen(getenv("LKFLOW_STAMPS_OUT"), "wb");
+            if (f) { fwrite(h.data(), 8, dn, f); fclose(f); }
+            return LKFLOW_OK;
+        }
+    }
+#endif
+    if (has_up) hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true>), grid, dim3(C::NT), 0, s, a);
+    else hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, false>), grid, dim3(C::NT), 0, s, a);
+    return LKFLOW_OK;
+}
+
+// -1: this window has no wave-specialised instantiation
+int launch_split(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, int win, hipStream_t s)
+{
+    switch (win) {
+#define SP_CASE(WN, KK) case WN: return launch_split_win<WN, KK>(ctx, a, has_up, pairs, s);
+#ifdef LKFLOW_FAST_BUILD
+#ifndef LK_SPLIT_K15
+#define LK_SPLIT_K15 2
+#endif
+        SP_CASE(15, LK_SPLIT_K15) SP_CASE(21, 2)
+#else
+        SP_CASE(5, 2) SP_CASE(7, 2) SP_CASE(9, 2) SP_CASE(11, 2) SP_CASE(13, 2) SP_CASE(15, 2)
+        SP_CASE(17, 2) SP_CASE(19, 2) SP_CASE(21, 2) SP_CASE(23, 2) SP_CASE(25, 2) SP_CASE(27, 2) SP_CASE(29, 2) SP_CASE(31, 2)
+#endif
+#undef SP_CASE
+        default: return -1;
+    }
+}
+
 // 3 x 3 windows on even-width levels: two columns per lane (lk_w3x2.h)
 int launch_w3x2(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
 {
-    static int bpc[2] = {0, 0};
-    if (bpc[has_up] == 0) {
-        int n = 0;
-        const hipError_t e = has_up ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lk::lk_w3x2_kernel<true>, 64, 0)
-                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lk::lk_w3x2_kernel<false>, 64, 0);
-        bpc[has_up] = (e == hipSuccess && n >= 1) ? n : 1;
-    }
+    const int bpc = has_up ? blocks_per_cu(ctx, lk::lk_w3x2_kernel<true>, 64) : blocks_per_cu(ctx, lk::lk_w3x2_kernel<false>, 64);
     const int gx = (a.W + lk::W3X2_XO - 1) / lk::W3X2_XO;
-    int th = ctx->tile_rows > 0 ? ctx->tile_rows : pick_tile_rows(a.H, 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc[has_up]);
+    int th = ctx->tile_rows > 0 ? ctx->tile_rows : pick_tile_rows(a.H, 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
     if (th > a.H) th = a.H;
     {
         const long long pmax = std::max(a.i1.pitch, std::max(a.u.pitch, a.v.pitch));
@@ -291,11 +352,7 @@ bool fused_w3_applies(const lkflow_ctx *ctx, int win, int W, int H)
 }
 int launch_w3x2f(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
 {
-    static int bpc = 0;
-    if (bpc == 0) {
-        int n = 0;
-        bpc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lk::lk_w3x2f_kernel, 64, 0) == hipSuccess && n >= 1) ? n : 1;
-    }
+    const int bpc = blocks_per_cu(ctx, lk::lk_w3x2f_kernel, 64);
     const int gx = (a.W + lk::W3X2_XO - 1) / lk::W3X2_XO;
     int th = ctx->tile_rows > 0 ? ctx->tile_rows : pick_tile_rows(a.H, 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
     if (th > a.H) th = a.H;
@@ -317,7 +374,7 @@ int launch_lk3(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, int
     switch (win) {
 #define LK_CASE(WN) case WN: return launch_lk3_win<WN, TX>(ctx, a, has_up, pairs, s);
 #ifdef LKFLOW_FAST_BUILD   /* A/B experiment builds: only the windows the goldens / headline use */
-        LK_CASE(3) LK_CASE(5) LK_CASE(9) LK_CASE(13) LK_CASE(15)
+        LK_CASE(3) LK_CASE(5) LK_CASE(9) LK_CASE(13) LK_CASE(15) LK_CASE(21)
 #else
         LK_CASE(3) LK_CASE(5) LK_CASE(7) LK_CASE(9) LK_CASE(11) LK_CASE(13) LK_CASE(15) LK_CASE(17)
         LK_CASE(19) LK_CASE(21) LK_CASE(23) LK_CASE(25) LK_CASE(27) LK_CASE(29) LK_CASE(31)
@@ -355,7 +412,12 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
         static const bool no_x2 = getenv("LKFLOW_NO_W3X2") != nullptr;            // debug knob (A/B)
         if (win == 3 && !no_x2 && a.W >= 2 && !(a.W & 1)) rc = launch_w3x2(ctx, a, has_up, pairs, s);   // 2 columns per lane
         else if (win == 3 && !no_w3) rc = launch_lk3_win<3, 64>(ctx, a, has_up, pairs, s);   // barrier-free DPP kernel
-        else rc = use128 ? launch_lk3<128>(ctx, a, has_up, pairs, win, s) : launch_lk3<256>(ctx, a, has_up, pairs, win, s);
+        else {
+            static const int split = getenv("LKFLOW_SPLIT") ? atoi(getenv("LKFLOW_SPLIT")) : 1;   // debug knob (A/B): 0 = one-role kernel
+            rc = (split && win >= 5) ? launch_split(ctx, a, has_up, pairs, win, s) : -1;
+            if (rc == -1)
+                rc = use128 ? launch_lk3<128>(ctx, a, has_up, pairs, win, s) : launch_lk3<256>(ctx, a, has_up, pairs, win, s);
+        }
 #endif
         if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
