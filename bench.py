@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Mpixels/s of dense pyramidal LK on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--config 1080p|4k|8k|pacman]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--config 1080p|4k|8k|pacman|webcam]
 
 One "step" = one pass of the hot path (lkflow_compute_batch_f64_dev: pyramids, coarse-to-fine
 warp + LK) over one batch of P synthetic frame pairs that are already resident in HBM.
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); frame pairs are sharded, each
 rank owns P pairs (weak scaling) and there is NO collective on the data path -- only the
-barriers that bracket the timed region.
+barriers that bracket the timed region.  Started without torch.distributed.run, `--gpus N` spawns
+the N ranks itself (fresh child processes, before anything touches a GPU) and relays rank 0's line.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,22 +45,25 @@ def level_sizes(cols, rows, levels):
     return out
 
 
-def algorithmic_bytes_per_pair(cols, rows, levels):
-    """B_alg = sum_{l>=1} 2s(N_{l-1}+N_l) + sum_l s(4N_l + 2N_{l+1}), s = 8."""
+def algorithmic_bytes_per_pair(cols, rows, levels, stream_pairs=0):
+    """B_alg = sum_{l>=1} 2s(N_{l-1}+N_l) + sum_l s(4N_l + 2N_{l+1}), s = 8.
+    stream_pairs = P > 0: the P pairs are consecutive frames of ONE stream, whose P+1 pyramids are built once
+    (not 2P): the pyramid term becomes (P+1)/P * s(N_{l-1}+N_l) per pair."""
     n = [r * c for r, c in level_sizes(cols, rows, levels)] + [0]
     s = 8
-    return sum(2 * s * (n[l - 1] + n[l]) for l in range(1, levels)) + \
+    frames_per_pair = (stream_pairs + 1) / stream_pairs if stream_pairs else 2.0
+    return int(sum(frames_per_pair * s * (n[l - 1] + n[l]) for l in range(1, levels))) + \
         sum(s * (4 * n[l] + 2 * n[l + 1]) for l in range(levels))
 
 
-def lk0_bytes_per_pair(cols, rows, levels):
+def lk0_bytes_per_pair(cols, rows, levels, fused=False):
     """Algorithmic bytes of the dominant kernel (LK at level 0): read 2 images, read the coarse
-    u,v (N0/4 each), write u,v  = s(4 N0 + 2 N1)."""
+    u,v (N0/4 each), write u,v  = s(4 N0 + 2 N1).  (The fused 3x3 kernel reads the UN-warped images: same count.)"""
     n = [r * c for r, c in level_sizes(cols, rows, levels)] + [0]
     return 8 * (4 * n[0] + 2 * n[1])
 
 
-def measured_traffic(kernel_prefix, cols, rows, pairs):
+def measured_traffic(kernel_name, cols, rows, pairs):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
     (profiles/pmc_traffic.json, written by tools/prof_pmc.sh for THIS workload), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -68,12 +74,103 @@ def measured_traffic(kernel_prefix, cols, rows, pairs):
         return None
     if d.get("_workload") != f"{cols}x{rows}x{pairs}":
         return None
-    best = None
-    for k, v in d.items():                        # the block width (128/256) is chosen per level by the library
-        if isinstance(v, dict) and k.startswith(kernel_prefix) and k.endswith(", true>"):
-            b = int(v["hbm_read_bytes"] + v["hbm_write_bytes"])
-            best = b if best is None else max(best, b)
-    return best
+    v = d.get(kernel_name)
+    return int(v["hbm_read_bytes"] + v["hbm_write_bytes"]) if isinstance(v, dict) else None
+
+
+def usable_cores():
+    """Cores this process may really run on: the affinity mask, cut by a cgroup CPU quota if one is set
+    (omp_get_max_threads() reports the machine's hardware threads, which a container may not own)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:                                                     # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                                 # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    eff = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return eff, n, quota
+
+
+# ---------------------------------------------------------------------------------------------------
+# one measured configuration (headline and the extra config objects share this)
+# ---------------------------------------------------------------------------------------------------
+def make_inputs(torch, synth, name, P, rows, cols, dev, seed):
+    if name in VIDEO_CONFIGS:
+        frames = synth.video_torch(P + 1, rows, cols, dev, seed=seed)
+        return frames[:-1], frames[1:]
+    return synth.frame_pairs_torch(P, rows, cols, dev, seed=seed)
+
+
+def roofline_objects(lkf, name, cols, rows, levels, win, P, pairs_per_launch, lk0_ms, lk0_n, dt, steps):
+    lk0_avg_s = lk0_ms / lk0_n / 1e3
+    kname = lkf.lk_kernel_name(rows, cols, win, has_up=levels > 1, fused_ok=True)
+    lk0_bytes = lk0_bytes_per_pair(cols, rows, levels, "w3x2f" in kname) * pairs_per_launch
+    achieved = lk0_bytes / lk0_avg_s
+    b_alg = algorithmic_bytes_per_pair(cols, rows, levels, P if name in VIDEO_CONFIGS else 0)
+    path_achieved = b_alg * P * steps / dt          # per GPU
+    roof = {
+        "kernel": f"{kname} (LK at pyramid level 0" + (", warp fused" if "w3x2f" in kname else "") + ")",
+        "bound": "hbm",
+        "achieved": round(achieved / 1e9, 2),
+        "peak": HBM_PEAK / 1e9,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK, 4),
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, gfx950 x2
+        # FETCH_SIZE correction applied; committed under profiles/), null if not collected for this workload
+        "traffic": measured_traffic(kname, cols, rows, pairs_per_launch),
+        "algorithmic_bytes_per_launch": lk0_bytes,
+        "avg_launch_ms": round(lk0_avg_s * 1e3, 4),
+        "launches_timed": lk0_n,
+        "pairs_per_launch": pairs_per_launch,
+    }
+    path = {
+        "algorithmic_bytes_per_pair": b_alg,
+        "achieved_GBps_per_gpu": round(path_achieved / 1e9, 2),
+        "frac_of_8TBps": round(path_achieved / HBM_PEAK, 4),
+    }
+    return roof, path, achieved, path_achieved
+
+
+def extra_config(lkf, torch, synth, name, device, steps=10, warmup=2):
+    """Extra objects `config_4k` / `config_webcam`: the same measurement as the headline on another
+    BASELINE shape, single stream, device-resident, with its own level-0 roofline from HIP events."""
+    cols, rows, levels, win, P = CONFIGS[name]
+    dev = torch.device("cuda", device)
+    prev, nxt = make_inputs(torch, synth, name, P, rows, cols, dev, 4321)
+    U, V = torch.empty_like(prev), torch.empty_like(prev)
+    ctx = lkf.Context(device)
+    ctx.reserve(rows, cols, levels, P)
+    stream = torch.cuda.current_stream()
+    for _ in range(warmup):
+        ctx.compute_batch(prev, nxt, levels, win, out=(U, V), stream=stream)
+    torch.cuda.synchronize()
+    ctx.profile(lkf.LKFLOW_STAGE_LK, 0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.compute_batch(prev, nxt, levels, win, out=(U, V), stream=stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    ctx.close()
+    lk0_ms, lk0_n = prof[(lkf.LKFLOW_STAGE_LK, 0)]
+    roof, path, _, _ = roofline_objects(lkf, name, cols, rows, levels, win, P, P, lk0_ms, lk0_n, dt, steps)
+    del prev, nxt, U, V
+    torch.cuda.empty_cache()
+    return {"workload": f"{cols}x{rows} L{levels} w{win}, {P} " + ("consecutive pairs of one stream" if name in VIDEO_CONFIGS else "independent pairs") +
+                        " per step, device-resident, 1 GPU",
+            "value": round(P * rows * cols * steps / dt / 1e6, 2), "unit": "Mpixels/s",
+            "frame_pairs_per_s": round(P * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "roofline": roof, "path_roofline": path,
+            "note": "rank 0 only, extra measurement after the timed region (not `value`)"}
 
 
 def pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, device, world, chunks=4, steps=20):
@@ -170,8 +267,10 @@ def copy_ceiling(torch, device, nbytes=2 << 30, reps=10):
 
 
 def host_call_rate(ctx, cols, rows, levels, win, reps=5):
-    """Extra: the host-buffer drop-in call (lkflow_compute_f64 = the cv::Mat entry point): pageable host arrays in,
-    host arrays out, synchronous -- i.e. the PCIe-inclusive rate of one pair.  Never `value`."""
+    """Extra: the host-buffer drop-in calls (the cv::Mat entry points): host arrays in, host arrays out, synchronous --
+    i.e. the PCIe-inclusive rate of one pair.  Never `value`.  f64 = lkflow_compute_f64 (CV_64F frames, 8 B/px up),
+    u8 = lkflow_compute_u8 (8-bit frames, convertTo(1/255) on the device, 1 B/px up)."""
+    import numpy as np
     import synth
     a, b = synth.frame_pair(rows, cols, seed=99)
     ctx.computeFlow(a, b, levels, win)
@@ -179,16 +278,31 @@ def host_call_rate(ctx, cols, rows, levels, win, reps=5):
     for _ in range(reps):
         ctx.computeFlow(a, b, levels, win)
     dt = (time.perf_counter() - t0) / reps
-    return {"ms_per_pair": round(dt * 1e3, 3), "Mpixels_per_s": round(rows * cols / dt / 1e6, 1),
-            "bytes_over_pcie_per_pair": 4 * rows * cols * 8,
-            "note": "rank 0 only, extra: 2 planes H2D + 2 planes D2H from pageable memory around the same kernels"}
+    out = {"ms_per_pair": round(dt * 1e3, 3), "Mpixels_per_s": round(rows * cols / dt / 1e6, 1),
+           "bytes_over_pcie_per_pair": 4 * rows * cols * 8,
+           "note": "rank 0 only, extra: 2 planes H2D + 2 planes D2H through the context's pinned bounce buffers "
+                   "around the same kernels"}
+    if hasattr(ctx, "computeFlow_u8"):
+        a8 = np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)
+        b8 = np.clip(np.rint(b * 255.0), 0, 255).astype(np.uint8)
+        ctx.computeFlow_u8(a8, b8, levels, win)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.computeFlow_u8(a8, b8, levels, win)
+        dt8 = (time.perf_counter() - t0) / reps
+        out["u8_in"] = {"ms_per_pair": round(dt8 * 1e3, 3), "Mpixels_per_s": round(rows * cols / dt8 / 1e6, 1),
+                        "bytes_over_pcie_per_pair": 2 * rows * cols + 2 * rows * cols * 8}
+    return out
 
 
 def cpu_baseline(cols, rows, levels, win, budget_s=20.0):
-    """Times oracle/lk_cpu_omp.c (the restated ParallelVideoPyr.cpp CPU path) on this host."""
+    """Times oracle/lk_cpu_omp.c (the restated ParallelVideoPyr.cpp CPU path) on this host's USABLE cores."""
     import synth
     from oracle import oracle as O
     O.build()
+    cores, affinity, quota = usable_cores()
+    omp_max = O.omp_lib().lkc_num_threads()
+    O.omp_lib().lkc_set_num_threads(cores)                # mode 1's row loops use omp_get_max_threads()
     a, b = synth.frame_pair(rows, cols, seed=1234)
     O.omp_coarse_to_fine(a[:64, :64].copy(), b[:64, :64].copy(), 1, 3, 0)   # thread pool warm-up
     res = {}
@@ -201,14 +315,76 @@ def cpu_baseline(cols, rows, levels, win, budget_s=20.0):
             if dt > budget_s * (0.6 if mode == 0 else 0.3) or n >= 96:
                 break
         res[mode] = (n * rows * cols / dt / 1e6, n, dt, name)
-    cores = O.omp_lib().lkc_num_threads()
     return {
         "value": round(res[0][0], 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
         "sample": f"{res[0][1]} pair(s) of {cols}x{rows} L{levels} w{win} in {res[0][2]:.1f}s with "
                   f"oracle/lk_cpu_omp.c mode 0 (ParallelVideoPyr.cpp's 2/3/5-way tasks + 8-thread row loops)",
         "all_cores_row_parallel_value": round(res[1][0], 4),
         "all_cores_sample": f"{res[1][1]} pair(s) in {res[1][2]:.1f}s, mode 1, {cores} threads",
+        "core_accounting": {"usable_cores": cores, "sched_affinity": affinity, "cgroup_cpu_quota": quota,
+                            "omp_get_max_threads_before_pinning": omp_max},
     }
+
+
+# ---------------------------------------------------------------------------------------------------
+# N > 1: a real stream through the frame queue: scatter uint8 frames from the ingest rank,
+# flow of each rank's consecutive pairs, gather of the 3-scalar centroid rows.  Reported apart from `value`.
+# ---------------------------------------------------------------------------------------------------
+def stream_sharding_extra(lkf, torch, dist, synth, ctx, name, dev, rank, world, frames_per_rank=0, reps=3):
+    import sharding
+    cols, rows, levels, win, P = CONFIGS[name]
+    per = frames_per_rank or min(P, 16)
+    F = per * world + 1
+    frames = None
+    if rank == 0:
+        g = torch.Generator(device="cpu").manual_seed(5)
+        base = synth.video_torch(F, rows, cols, dev, seed=77)
+        frames = (base * 255.0).round().clamp_(0, 255).to(torch.uint8)
+        del base
+    t_sc = t_cp = t_ga = 0.0
+    rows_root = None
+    for it in range(reps + 1):
+        torch.cuda.synchronize(); dist.barrier(); t0 = time.perf_counter()
+        local = sharding.scatter_frames(frames, F, rows, cols, src=0, device=dev)
+        torch.cuda.synchronize(); dist.barrier(); t1 = time.perf_counter()
+        _, _, cent = sharding.stream_flow(local, ctx, levels, win, keep_flow=False)
+        torch.cuda.synchronize(); dist.barrier(); t2 = time.perf_counter()
+        rows_root = sharding.gather_rows(cent, F, dst=0)
+        torch.cuda.synchronize(); dist.barrier(); t3 = time.perf_counter()
+        if it:                                              # first pass = warm-up (communicator set-up, workspace)
+            t_sc += t1 - t0; t_cp += t2 - t1; t_ga += t3 - t2
+    if rank != 0:
+        return None
+    npx = (F - 1) * rows * cols
+    return {"frames": F, "pairs": F - 1, "shape": [rows, cols], "pyr_levels": levels, "win": win, "reps": reps,
+            "scatter_ms": round(t_sc / reps * 1e3, 3), "scatter_GBps": round(F * rows * cols / (t_sc / reps) / 1e9, 2),
+            "compute_ms": round(t_cp / reps * 1e3, 3), "compute_Mpixels_per_s": round(npx / (t_cp / reps) / 1e6, 2),
+            "gather_ms": round(t_ga / reps * 1e3, 3), "rows_gathered": list(rows_root.shape),
+            "end_to_end_Mpixels_per_s": round(npx / ((t_sc + t_cp + t_ga) / reps) / 1e6, 2),
+            "note": "strong-scaling stream mode, extra (not `value`): rank 0 holds the uint8 stream; point-to-point "
+                    "scatter over RCCL (1-frame overlap per shard), convertTo + flow + fused centroid per rank, "
+                    "gather of 3 scalars per pair; each phase bracketed by barriers"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this parent has not
+    touched a GPU and never will), relay rank 0's JSON line, exit with the worst child status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    raise SystemExit(rc)
 
 
 def main():
@@ -221,7 +397,7 @@ def main():
     ap.add_argument("--win", type=int, default=0, help="override the config's window (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="only the timed region (no cpu_baseline, no pipelined pass): use under rocprofv3")
+                    help="only the timed region (no cpu_baseline, no extra objects): use under rocprofv3")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time of every stage")
     ap.add_argument("--inflight", type=int, default=1,
                     help="split each step's batch over this many contexts/streams that run unsynchronised "
@@ -230,6 +406,9 @@ def main():
                     help="capture one step into a HIP graph and replay it (launch-bound small batches); "
                          "the per-kernel HIP-event roofline is then taken from a separate eager pass")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)                               # never returns
 
     import torch
     import lkflow_amd as lkf
@@ -242,10 +421,7 @@ def main():
     rehearse = os.environ.get("LKFLOW_BENCH_REHEARSE_ONE_GPU") == "1"
     if rehearse:
         local_rank = 0
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dist = None
@@ -264,11 +440,7 @@ def main():
 
     # synthetic translated-noise input generated in HBM (each rank: its own shard).  BASELINE configs 3 and 4 are
     # STREAMS (consecutive pairs of one frame sequence): P+1 frames, pair p = frames p, p+1; the others are pairs.
-    if args.config in VIDEO_CONFIGS:
-        frames = synth.video_torch(P + 1, rows, cols, dev, seed=1234 + rank)
-        prev, nxt = frames[:-1], frames[1:]
-    else:
-        prev, nxt = synth.frame_pairs_torch(P, rows, cols, dev, seed=1234 + rank)
+    prev, nxt = make_inputs(torch, synth, args.config, P, rows, cols, dev, 1234 + rank)
     U = torch.empty_like(prev)
     V = torch.empty_like(prev)
     ctx = lkf.Context(local_rank)
@@ -344,16 +516,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
+    stream_extra = None
+    if dist is not None and not args.no_extras and not rehearse:
+        del prev, nxt, U, V
+        torch.cuda.empty_cache()
+        stream_extra = stream_sharding_extra(lkf, torch, dist, synth, ctx, args.config, dev, rank, world)
+        prev = nxt = U = V = None
+
     if rank == 0:
         px_per_step = P * rows * cols * world
         value = px_per_step * args.steps / dt / 1e6
         lk0_ms, lk0_n = prof[(lkf.LKFLOW_STAGE_LK, 0)]
-        lk0_avg_s = lk0_ms / lk0_n / 1e3
         pairs_per_launch = P if K == 1 else P // K          # events are on chunk 0's context
-        lk0_bytes = lk0_bytes_per_pair(cols, rows, levels) * pairs_per_launch
-        achieved = lk0_bytes / lk0_avg_s
-        b_alg = algorithmic_bytes_per_pair(cols, rows, levels)
-        path_achieved = b_alg * P * args.steps / dt          # per GPU
+        roof, path, achieved, path_achieved = roofline_objects(lkf, args.config, cols, rows, levels, win, P,
+                                                               pairs_per_launch, lk0_ms, lk0_n, dt, args.steps)
+        lk0_avg_s = lk0_ms / lk0_n / 1e3
         out = {
             "metric": f"Mpixels/s (dense LK, {levels}-level pyr, {win}x{win} win)",
             "value": round(value, 2),
@@ -380,43 +557,31 @@ def main():
                 "chunks_in_flight": K,
             },
             "frame_pairs_per_s": round(P * world * args.steps / dt, 2),
-            "roofline": {
-                "kernel": f"lk_march3_kernel<{win},TX,true> (LK at pyramid level 0; TX = 128 or 256 columns per block, "
-                          f"picked per level by the library)",
-                "bound": "hbm",
-                "achieved": round(achieved / 1e9, 2),
-                "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK, 4),
-                # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, gfx950 x2
-                # FETCH_SIZE correction applied; committed under profiles/), null if not collected
-                "traffic": measured_traffic(f"lk::lk_march3_kernel<{win}, ", cols, rows, pairs_per_launch),
-                "algorithmic_bytes_per_launch": lk0_bytes,
-                "avg_launch_ms": round(lk0_avg_s * 1e3, 4),
-                "launches_timed": lk0_n,
-                "pairs_per_launch": pairs_per_launch,
-            },
-            "path_roofline": {
-                "algorithmic_bytes_per_pair": b_alg,
-                "achieved_GBps_per_gpu": round(path_achieved / 1e9, 2),
-                "frac_of_8TBps": round(path_achieved / HBM_PEAK, 4),
-            },
+            "roofline": roof,
+            "path_roofline": path,
         }
         if args.profile_all:
             names = {0: "pyrdown", 1: "warp", 2: "lk"}
             out["stage_ms_per_step"] = {f"{names[s]}_L{l}": round(ms / args.steps, 4)
                                         for (s, l), (ms, n) in sorted(prof.items())}
+        if stream_extra is not None:
+            out["stream_sharding"] = stream_extra
         if world == 1 and K == 1 and not args.graph and P >= 8 and not args.no_extras:
             out["pipelined"] = pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, local_rank, world)
         if world == 1 and not args.no_extras:
+            del prev, nxt, U, V
+            torch.cuda.empty_cache()
             ceil_bps = copy_ceiling(torch, local_rank)
             out["copy_ceiling"] = {"GBps": round(ceil_bps / 1e9, 1), "what": "torch device-to-device copy of 2 GiB (hipMemcpy path), bytes read + written; a hand-written float4 "
                                            "copy kernel reaches 6.29 TB/s on this part (MI355X_MICROARCH.md)",
                                    "lk0_algorithmic_frac": round(achieved / ceil_bps, 4),
-                                   "lk0_traffic_frac": (round(out["roofline"]["traffic"] / lk0_avg_s / ceil_bps, 4)
-                                                        if out["roofline"]["traffic"] else None),
+                                   "lk0_traffic_frac": (round(roof["traffic"] / lk0_avg_s / ceil_bps, 4)
+                                                        if roof["traffic"] else None),
                                    "path_algorithmic_frac": round(path_achieved / ceil_bps, 4)}
             out["host_buffer_call"] = host_call_rate(ctx, cols, rows, levels, win)
+            if args.config == "1080p":                       # the other BASELINE shapes, in the driver's record
+                out["config_4k"] = extra_config(lkf, torch, synth, "4k", local_rank)
+                out["config_webcam"] = extra_config(lkf, torch, synth, "webcam", local_rank)
             out["preprocess"] = preprocess_rate(ctx, torch, local_rank)
             out["video_pipeline"] = video_pipeline_rate(lkf, torch, local_rank)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:

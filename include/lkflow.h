@@ -58,6 +58,11 @@ const char *lkflow_strerror(int status);
 const char *lkflow_last_error(const lkflow_ctx *ctx);
 /* Library version string. */
 const char *lkflow_version(void);
+/* Diagnostics / measurement: the name (as rocprofv3 prints it) of the LK kernel the library launches for one
+ * pyramid level of rows x cols with window `win`; has_up = the level is below the coarsest (it adds the
+ * up-sampled coarse flow), fused_ok = the call does not need the level's warped images in memory
+ * (i.e. not level 0 of a LKFLOW_MUTATE_INPUTS call).  bench.py labels its roofline with it. */
+int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok, char *buf, size_t n);
 
 /* One context per GPU and caller thread: owns the device workspace (pyramids, per-level flow). */
 int lkflow_ctx_create(lkflow_ctx **out, int device);
@@ -71,6 +76,11 @@ int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int 
 #define LKFLOW_OPT_PROFILE 3   /* 0 = off (default); -1 = bracket EVERY kernel launch with HIP events on
                                   its own stream; 1 + stage*32 + level = only that (stage, level).
                                   Read back with lkflow_ctx_profile_read. */
+#define LKFLOW_OPT_PIN_HOST 4  /* 0 (default) / 1: page-lock the caller's host buffers in place (hipHostRegister, cached in
+                                  the context, released by value 0 or lkflow_ctx_destroy) so that the host-buffer entry
+                                  points move data by asynchronous DMA instead of the pageable path.  ONLY for buffers that
+                                  outlive the context or are re-used call after call (a video loop's Mats): a registered
+                                  buffer must not be freed while the option is on. */
 int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value);
 
 /* Stage ids of the kernels the pyramid driver launches (level = pyramid level the launch works at;
@@ -94,6 +104,28 @@ size_t lkflow_ctx_workspace_bytes(const lkflow_ctx *ctx);
 int lkflow_compute_f64(lkflow_ctx *ctx, double *prev, double *next, int rows, int cols,
                        size_t step_bytes, double *U, double *V, size_t uv_step_bytes,
                        int pyr_levels, int win, unsigned flags);
+
+/*
+ * The same call for 8-bit frames (what SerialPyr.cpp:223-238 loads before convertTo(CV_64FC1, 1.0/255)): the
+ * conversion runs on the device (exactly double(p) * (1.0/255)), so 1 byte per pixel crosses PCIe instead of 8.
+ * Inputs are never written (no LKFLOW_MUTATE_INPUTS: a CV_8U frame cannot hold the warped CV_64F image).
+ */
+int lkflow_compute_u8(lkflow_ctx *ctx, const unsigned char *prev, const unsigned char *next, int rows, int cols,
+                      size_t step_bytes, double *U, double *V, size_t uv_step_bytes, int pyr_levels, int win);
+
+/*
+ * Asynchronous forms of the two host-buffer calls: everything -- upload, pyramid, download -- is
+ * enqueued on the context's own stream and the call returns; lkflow_wait() blocks until U, V (and, with
+ * LKFLOW_MUTATE_INPUTS, prev/next) are complete.  The host buffers must stay valid and untouched until then.
+ * One pair per context may be in flight (a second enqueue first waits for the first); use two contexts to overlap
+ * the transfers of one pair with the kernels of another.  With pageable host memory the runtime's copies are
+ * staged and partly synchronous; with LKFLOW_OPT_PIN_HOST (or hipHostMalloc'ed buffers) they are true async DMA.
+ */
+int lkflow_enqueue_pair_f64(lkflow_ctx *ctx, double *prev, double *next, int rows, int cols, size_t step_bytes,
+                            double *U, double *V, size_t uv_step_bytes, int pyr_levels, int win, unsigned flags);
+int lkflow_enqueue_pair_u8(lkflow_ctx *ctx, const unsigned char *prev, const unsigned char *next, int rows, int cols,
+                           size_t step_bytes, double *U, double *V, size_t uv_step_bytes, int pyr_levels, int win);
+int lkflow_wait(lkflow_ctx *ctx);
 
 /* getLucasKanadeOpticalFlow on HOST buffers (ParallelVideoPyr.cpp:327), window generalised. */
 int lkflow_lk_f64(lkflow_ctx *ctx, const double *img1, const double *img2, int rows, int cols,

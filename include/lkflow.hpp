@@ -102,22 +102,46 @@ public:
     void computeFlow(const Mat &prev, const Mat &next, Mat &U, Mat &V, int pyr_levels, int win = 3,
                      unsigned flags = 0)
     {
-        check_pair(prev, next);
-        mat_create(U, prev.rows, prev.cols);     // the reference re-seats u,v to new H x W buffers (:639-640)
-        mat_create(V, prev.rows, prev.cols);
-        check(lkflow_compute_f64(ctx_, mat_data(prev), mat_data(next), prev.rows, prev.cols, mat_step(prev),
-                                 mat_data(U), mat_data(V), mat_step(U), pyr_levels, win, flags));
+        enqueue(prev, next, U, V, pyr_levels, win, flags);
+        wait();
     }
+    // Asynchronous form: upload, pyramid and download are enqueued on the engine's stream;
+    // wait() completes U and V.  prev, next, U, V must stay alive and untouched until then.  One pair per
+    // engine may be in flight; two engines overlap the transfers of one pair with the kernels of another.
+    void enqueue(const Mat &prev, const Mat &next, Mat &U, Mat &V, int pyr_levels, int win = 3, unsigned flags = 0)
+    {
+        check_pair(prev, next);
+        seat_outputs(U, V, prev.rows, prev.cols);
+        check(lkflow_enqueue_pair_f64(ctx_, mat_data(prev), mat_data(next), prev.rows, prev.cols, mat_step(prev),
+                                      mat_data(U), mat_data(V), mat_step(U), pyr_levels, win, flags));
+    }
+    void wait() { check(lkflow_wait(ctx_)); }
+    // Page-lock the (re-used) Mats of a video loop in place: see LKFLOW_OPT_PIN_HOST in lkflow.h.
+    void pinHostBuffers(bool on) { check(lkflow_ctx_set_option(ctx_, LKFLOW_OPT_PIN_HOST, on ? 1 : 0)); }
+
     void getLucasKanadeOpticalFlow(const Mat &img1, const Mat &img2, Mat &u, Mat &v, int win = 3)
     {
         check_pair(img1, img2);
-        mat_create(u, img1.rows, img1.cols);
-        mat_create(v, img1.rows, img1.cols);
+        seat_outputs(u, v, img1.rows, img1.cols);
         check(lkflow_lk_f64(ctx_, mat_data(img1), mat_data(img2), img1.rows, img1.cols, mat_step(img1),
                             mat_data(u), mat_data(v), mat_step(u), win));
     }
 
 private:
+    // The reference re-seats u, v to new H x W buffers (`u = tmpu`, :639-640).  cv::Mat::create keeps a matrix
+    // of matching size and type as it is -- including a caller's ROI / padded rows, whose step the C ABI's one
+    // uv_step_bytes cannot describe when U and V differ: such outputs are re-seated to fresh continuous
+    // matrices (which is what the reference's header assignment amounts to).
+    static void seat_outputs(Mat &U, Mat &V, int rows, int cols)
+    {
+        mat_create(U, rows, cols);
+        mat_create(V, rows, cols);
+        if (mat_step(U) != mat_step(V) || mat_step(U) < (size_t)cols * sizeof(double) || mat_step(U) % sizeof(double)) {
+            U = Mat(); V = Mat();
+            mat_create(U, rows, cols);
+            mat_create(V, rows, cols);
+        }
+    }
     static void check_pair(const Mat &a, const Mat &b)
     {
         if (!mat_ok(a) || !mat_ok(b)) throw std::invalid_argument("lkflow: images must be non-empty CV_64FC1");
@@ -159,6 +183,27 @@ inline void coarseToFineEstimation(Mat &img1, Mat &img2, Mat &u, Mat &v, int nLe
 inline void getLucasKanadeOpticalFlow(Mat &img1, Mat &img2, Mat &u, Mat &v)
 {
     default_engine().getLucasKanadeOpticalFlow(img1, img2, u, v, 3);
+}
+
+// ---- host tail of the flow consumer (ParallelVideoPyr.cpp:875-888) ------------------------------------------
+// lkflow_flow_centroid_f64_dev returns, per pair, counts = #{|flow| >= thresh} and the sums of their column / row
+// indices (:845-873).  What the reference then does with them on the host: avgX /= counts, avgY /= counts (:875-876),
+// scale by the INTEGER ratio frame.cols / current_frame.cols (:878-883 -- the display frame over the working
+// frame, truncated as the reference's int division truncates) and draw the circle only if counts > 500 (:886).
+struct Gesture {
+    bool detected;      // counts > 500
+    double x, y;        // circle centre in display-frame pixels (valid when detected; 0, 0 for counts == 0)
+};
+inline Gesture gestureCentroid(double counts, double sum_x, double sum_y, int frame_cols, int work_cols,
+                               double min_counts = 500.0)
+{
+    Gesture g{counts > min_counts, 0.0, 0.0};
+    if (counts > 0.0) {
+        const int scale = work_cols > 0 ? frame_cols / work_cols : 1;     // int / int, as the reference
+        g.x = sum_x / counts * scale;
+        g.y = sum_y / counts * scale;
+    }
+    return g;
 }
 
 }  // namespace lkflow

@@ -169,9 +169,6 @@ struct WarpArgs {
     int th;           // rows per block (even)
 };
 
-#ifndef LK_WARP_VARIANT
-#define LK_WARP_VARIANT 2
-#endif
 #ifndef LK_WARP_WAVES
 #define LK_WARP_WAVES 1
 #endif
@@ -229,26 +226,13 @@ __global__ __launch_bounds__(256, LK_WARP_WAVES) void warp_kernel(WarpArgs a)
         const float hx0 = (float)upu0 / 2, hy0 = (float)upv0 / 2, hx1 = (float)upu1 / 2, hy1 = (float)upv1 / 2;
         const float yf0 = (float)y, yf1 = (float)(y + 1);
         const int so1 = (y - y0) * op1b, so2 = (y - y0) * op2b;
-#if LK_WARP_VARIANT == 0
-        buf_st(rO1, x8, so1, remap_bilinear(I1, ip, H, W, xf + hx0, yf0 + hy0));
-        buf_st(rO2, x8, so2, remap_bilinear(I2, ip, H, W, xf - hx0, yf0 - hy0));
-        buf_st(rO1, x8, so1 + op1b, remap_bilinear(I1, ip, H, W, xf + hx1, yf1 + hy1));   // H is even: row y+1 exists
-        buf_st(rO2, x8, so2 + op2b, remap_bilinear(I2, ip, H, W, xf - hx1, yf1 - hy1));
-#elif LK_WARP_VARIANT == 1
-        const double a0 = remap_bilinear(I1, ip, H, W, xf + hx0, yf0 + hy0);
-        const double b0 = remap_bilinear(I2, ip, H, W, xf - hx0, yf0 - hy0);
-        buf_st(rO1, x8, so1, a0); buf_st(rO2, x8, so2, b0);
-        const double a1 = remap_bilinear(I1, ip, H, W, xf + hx1, yf1 + hy1);
-        const double b1 = remap_bilinear(I2, ip, H, W, xf - hx1, yf1 - hy1);
-        buf_st(rO1, x8, so1 + op1b, a1); buf_st(rO2, x8, so2 + op2b, b1);
-#else
+        // all four gathers in flight before the first store (H is even: row y+1 exists)
         const double a0 = remap_bilinear(I1, ip, H, W, xf + hx0, yf0 + hy0);
         const double b0 = remap_bilinear(I2, ip, H, W, xf - hx0, yf0 - hy0);
         const double a1 = remap_bilinear(I1, ip, H, W, xf + hx1, yf1 + hy1);
         const double b1 = remap_bilinear(I2, ip, H, W, xf - hx1, yf1 - hy1);
         buf_st(rO1, x8, so1, a0); buf_st(rO2, x8, so2, b0);
         buf_st(rO1, x8, so1 + op1b, a1); buf_st(rO2, x8, so2 + op2b, b1);
-#endif
         hu0 = hu1; hu1 = hu2; hv0 = hv1; hv1 = hv2;
     }
 }

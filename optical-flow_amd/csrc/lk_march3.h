@@ -264,12 +264,19 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
 #pragma unroll
                 for (int j = 0; j < R; ++j) h += q[j];
             }
-            // vertical van Herk / Gil-Werman step at static chunk position K
-            pre[f] = (K == 0) ? h : pre[f] + h;
-            S[f] = (K < WIN - 1) ? ring[(K + 1) % WIN][f] + pre[f] : pre[f];
-            if (K > 0) ring[K][f] = h;                          // slot 0 is never read back (see below)
+            if constexpr (WIN == 3) {
+                // three rows: summed directly, (row i-2 + row i-1) + row i -- one fixed order for every row, so the
+                // result does not depend on where a strip starts (see the chunk anchoring below)
+                S[f] = (ring[(K + 1) % 3][f] + ring[(K + 2) % 3][f]) + h;
+                ring[K][f] = h;
+            } else {
+                // vertical van Herk / Gil-Werman step at static chunk position K
+                pre[f] = (K == 0) ? h : pre[f] + h;
+                S[f] = (K < WIN - 1) ? ring[(K + 1) % WIN][f] + pre[f] : pre[f];
+                if (K > 0) ring[K][f] = h;                      // slot 0 is never read back (see below)
+            }
         }
-        if (K == WIN - 1) {
+        if (WIN > 3 && K == WIN - 1) {
 #pragma unroll
             for (int q = WIN - 2; q >= 1; --q)                  // suffix sums; suffix[0] (= chunk total) is never used
 #pragma unroll
@@ -333,9 +340,15 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
 #endif
     };
 
-    for (int base = 0; base < nmarch; base += WIN) {
+    // The van Herk chunks are anchored to ABSOLUTE image rows (chunk position of image row r = r mod WIN), not to
+    // the strip: the order in which the WIN rows of a window are added is then a property of the output row alone,
+    // so results do not depend on the strip height -- which the launcher picks from the batch size and the CU
+    // count -- and a sharded stream reproduces the unsharded one bit for bit.  WIN = 3 sums its
+    // three rows directly (no chunks; its queue slots are tied to K, so it keeps K = marched row mod 3).
+    const int kc0 = WIN == 3 ? 0 : ((yy0 % WIN) + WIN) % WIN;   // chunk position of marched row 0
+    for (int base = 0; base < nmarch + kc0; base += WIN) {
         [&]<int... Ks>(std::integer_sequence<int, Ks...>) __attribute__((always_inline)) {
-            ((base + Ks < nmarch ? (row(std::integral_constant<int, Ks>{}, base + Ks), 0) : 0), ...);
+            ((base + Ks >= kc0 && base + Ks < nmarch + kc0 ? (row(std::integral_constant<int, Ks>{}, base + Ks - kc0), 0) : 0), ...);
         }(std::make_integer_sequence<int, WIN>{});
     }
 #ifdef LK3_STAMPS

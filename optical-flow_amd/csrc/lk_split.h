@@ -9,9 +9,10 @@
 // instruction of ANY kind per 4 cycles, so its ~410 instructions per row are a >= 1640-cycle serial chain.
 // Here a block of K*64 columns is marched by three kinds of waves, each with a short instruction stream:
 //
-//   * K/2 "F" (front) waves, TWO adjacent columns per lane: image rows (one 16-byte load of the pair + one
-//     8-byte load of the left derivative tap per image and row, PF rows in flight, previous row in registers)
-//     -> fx, fy, ft -> the five products of both columns -> ONE ds_write_b128 per field.
+//   * one "F" (front) wave, TWO adjacent columns per lane: image rows (ONE 16-byte load of the pair per image
+//     and row, PF rows in flight, previous row in registers; the left derivative tap is the left lane's second
+//     pixel by a DPP wave shift -- lane 0 is a halo pair, so the wave feeds 126 columns) -> fx, fy, ft -> the
+//     five products of both columns -> ONE ds_write_b128 per field.
 //   * 5 "S" waves, one FIELD each, K adjacent columns per lane: the lane reads the raw products of columns
 //     [K*j - R, K*j + K-1 + R] as aligned 16-byte LDS reads (10 ds_read_b128 at K = 4, R = 7: 2.5 per output
 //     instead of 8 reads), forms the K horizontal windows with a shared core sum (21 adds for 4 outputs at
@@ -21,8 +22,10 @@
 //     ds_read_b64 per field) -> clipped-window rule, 2 x 2 solve with true fp64 divisions, /0 -> 0,
 //     "+= pyrUp(coarse flow)" from register-carried coarse rows (taps fetched two rows ahead), streaming store.
 //
-// The three stages run concurrently on different marched rows (F: row i, S: row i-1, B: row i-2) with
-// double-buffered LDS planes and ONE workgroup barrier per marched row.  Every vector-memory instruction is
+// The three stages run concurrently on different marched rows with double-buffered LDS planes; a pipeline STEP is
+// TWO marched rows (F: rows 2s, 2s+1; S: the two rows of step s-1; B: those of step s-2) and ends in ONE workgroup
+// barrier: the LDS round trips, the barrier and the dependent fp64 chains of the solve are paid once per two rows,
+// and a B wave interleaves the two independent solves of its row pair.  Every vector-memory instruction is
 // issued unconditionally (clamped rows; a store that must not happen gets an out-of-range buffer offset, which
 // the hardware drops): hipcc's s_waitcnt counting gives up on loads or stores under a condition and then drains
 // vmcnt(0) at every use, which serialises a step behind its own prefetch.
@@ -31,13 +34,13 @@
 //
 // Summation order: horizontal = tree over the shared core + short left/right chains, vertical = van Herk; only
 // additions (flat regions give exactly 0 like the reference); same products, solve and pyrUp expressions as
-// lk_march3.h.  Host-checked: W even, H > R + PF + 1, even strip height (row parity is static in the unrolled
-// pipeline); other shapes take lk_march3.h.
+// lk_march3.h.  Host-checked: W even, H > R + PF + 1, even strip height (a step's row pair is an even and an odd
+// output row); other shapes take lk_march3.h.
 #pragma once
 #include "lk_w3x2.h"     // buf_ld2 (16-byte buffer loads), lk_march3.h
 
 #ifndef LK_SPLIT_PF
-#define LK_SPLIT_PF 2
+#define LK_SPLIT_PF 4
 #endif
 
 #ifdef LK_SPLIT_STAMPS   /* diagnostic build: per-wave segment cycle totals -> a.dbg (tools/split_stamps_summary.py) */
@@ -57,8 +60,8 @@ struct SplitCfg {
     static constexpr int R = WIN / 2;
     static constexpr int PF = LK_SPLIT_PF;           // image rows in flight per F lane: a pipeline step is short, HBM latency is not
     static constexpr int NB = K;                     // B waves: 64 columns each
-    static constexpr int NF = K / 2;                 // F waves: 128 columns each
-    static constexpr int TXC = 64 * K;               // columns per block
+    static constexpr int NF = 1;                     // one F wave: lane 0 is a halo pair (left tap of lane 1), lanes 1..63 = 126 columns
+    static constexpr int TXC = 64 * K - 2;           // columns per block with products
     static constexpr int HL = R + (R & 1);           // halo columns on each side (even: a lane's column pair is 16-byte aligned)
     static constexpr int XO = TXC - 2 * HL;          // output columns per block
     static constexpr int NW = NB + 5 + NF;           // waves per block, in this order: B, S, F
@@ -77,10 +80,10 @@ struct SplitCfg {
 #else
     static constexpr int WPE = (K == 2 && WIN <= 21) ? 4 : 1;   // waves per SIMD to compile for (8-wave blocks: 4 -> two blocks per CU)
 #endif
-    static constexpr int UN = 2;                     // unrolled F group (LDS buffer parity, queue slot)
-    static_assert(K == 2 || K == 4, "S lanes own 2 or 4 columns");
+    static constexpr int UN = 2;                     // unrolled F group in steps (LDS buffer parity; queue slots of 4 rows)
+    static_assert(K == 2, "one F wave feeds 126 columns: S lanes own 2 columns (K = 4 ran one 11-wave block per CU: slower)");
     static_assert(PSTR >= NJP, "product half-planes must not overlap");
-    static_assert(UN % PF == 0, "static queue slots: PF is 1 or 2");
+    static_assert(PF == 2 || PF == 4, "static queue slots: two rows per step, two steps per group");
 };
 
 // tree sum of v[LO..HI] (compile-time bounds)
@@ -99,8 +102,8 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 {
     using C = SplitCfg<WIN, K>;
     constexpr int R = C::R, TXC = C::TXC, XO = C::XO, KH = C::KH, PADJ = C::PADJ, PF = C::PF, UN = C::UN, HL = C::HL;
-    __shared__ __attribute__((aligned(16))) double s_prod[2][5][C::PROD_D];
-    __shared__ __attribute__((aligned(16))) double s_sums[2][5][C::SUMS_D];
+    __shared__ __attribute__((aligned(16))) double s_prod[2][2][5][C::PROD_D];   // [step parity][row of the step][field]
+    __shared__ __attribute__((aligned(16))) double s_sums[2][2][5][C::SUMS_D];
 
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 #ifdef LK_SPLIT_STAMPS
@@ -110,18 +113,22 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
     const int H = a.H, W = a.W;
     const int y0 = blockIdx.y * a.th;                // even (host)
     const int y1 = min(y0 + a.th, H);
-    const int nm = (y1 - y0) + 2 * R;                // marched product rows: image rows y0-R .. y1-1+R
+    const int nrows = y1 - y0;                       // even (H is even or the strip height is: host)
+    const int nm = nrows + 2 * R;                    // marched product rows: image rows y0-R .. y1-1+R
     const int yy0 = y0 - R;
     const int x0 = (int)blockIdx.x * XO - HL;        // image column of block column 0 (even)
-    const int nit = 2 * R + 2 + (y1 - y0 + 3) / 4 * 4;   // pipeline steps (= barriers): fill + output rows padded to whole groups of 4
+    const int nsw = nm / 2;                          // steps in which F (and, one step later, S) has rows
+    const int ns = nsw + 2;                          // pipeline steps: B trails F by two
+    const int NS = ns + (ns & 1);                    // barriers per wave: padded to whole F groups (idle tail step)
 
     // zero the pad lanes of the product planes once (only non-output columns ever read them)
-    for (int k = threadIdx.x; k < 2 * 5 * KH * 2 * PADJ; k += C::NT) {
+    constexpr int PZ = PADJ + 1;                      // right side: the pads and the chunk of columns TXC, TXC + 1
+    for (int k = threadIdx.x; k < 4 * 5 * KH * 2 * PZ; k += C::NT) {
         const int side = k % 2, rest = k / 2;
-        const int pj = rest % PADJ, h = (rest / PADJ) % KH, f = (rest / (PADJ * KH)) % 5, b = rest / (PADJ * KH * 5);
-        const int chunk = h * C::PSTR + (side ? PADJ + 64 + pj : pj);
-        s_prod[b][f][2 * chunk] = 0.0;
-        s_prod[b][f][2 * chunk + 1] = 0.0;
+        const int pj = rest % PZ, h = (rest / PZ) % KH, f = (rest / (PZ * KH)) % 5, b = rest / (PZ * KH * 5);
+        const int chunk = h * C::PSTR + (side ? PADJ + 63 + pj : min(pj, PADJ - 1));
+        s_prod[b >> 1][b & 1][f][2 * chunk] = 0.0;
+        s_prod[b >> 1][b & 1][f][2 * chunk + 1] = 0.0;
     }
     __syncthreads();
 
@@ -129,18 +136,18 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         // =========================================================================================
         // F waves: two adjacent columns per lane -> products
         // =========================================================================================
-        const int m = (int)threadIdx.x - 64 * (C::NB + 5);   // column pair of the block: columns 2m, 2m + 1
-        const int xa = x0 + 2 * m;                   // even; W even: the pair is all in or all out
+        const int m = (int)threadIdx.x - 64 * (C::NB + 5);   // lane: block columns 2(m-1), 2(m-1)+1; lane 0 = the pair left of the block
+        const int xa = x0 + 2 * (m - 1);             // even; W even: the pair is all in or all out
         const int pitchb = (int)a.i1.pitch * 8;
         const bool col_in = xa >= 0 && xa < W;
+        const bool all_col_in = __builtin_amdgcn_ballot_w64(!col_in) == 0;
         const int xc = min(max(xa, 0), W - 2);
         const int row_lo = max(y0 - R - PF, 0);
         const long long img_bytes = ((long long)(H - 1 - row_lo) * a.i1.pitch + W) * 8;
         const __amdgpu_buffer_rsrc_t rI1 = buf_rsrc(a.i1.at(pair) + (long long)row_lo * a.i1.pitch, img_bytes);
         const __amdgpu_buffer_rsrc_t rI2 = buf_rsrc(a.i2.at(pair) + (long long)row_lo * a.i2.pitch, img_bytes);
         const int vxc = xc * 8;
-        const int vxl = (xc > 0 ? xc - 1 : 1) * 8;   // left derivative tap of column xa (reflect-101 at column 0)
-        const int p_chunk = KH == 1 ? PADJ + m : (m & 1) * C::PSTR + PADJ + (m >> 1);
+        const int p_chunk = PADJ + m - 1;            // (lane 0 lands in the last left pad chunk: real products, never summed into an output)
 
         // byte offset of image row yy: one reflection (exact for every row an output needs: H > R + PF + 1),
         // then clamped (prefetches of the idle tail steps run past the last needed row)
@@ -150,69 +157,81 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             rr = max(rr, row_lo);
             return (rr - row_lo) * pitchb;
         };
+        // left derivative tap of column xa for a row whose pair is (.., vb) in this lane: the left lane's second pixel.
+        // At image column 0 the left lane's pair is clamped to columns (0, 1), so it hands over column 1 = the
+        // reflect-101 tap (lane 0 of a wave never produces an output column: it is the halo pair).
+        auto left_tap = [&](double vb) __attribute__((always_inline)) { return dpp_wave_shr1(vb); };
         // previous row (p*) and current row (c*): left tap l, columns a and b; [0] image 1, [1] image 2
         double pl[2], pa[2], pb[2], cl[2], ca[2], cb[2];
         {
             int ro = img_row_off(yy0 - 1);
-            pl[0] = buf_ld(rI1, vxl, ro); buf_ld2(rI1, vxc, ro, pa[0], pb[0]);
-            pl[1] = buf_ld(rI2, vxl, ro); buf_ld2(rI2, vxc, ro, pa[1], pb[1]);
+            buf_ld2(rI1, vxc, ro, pa[0], pb[0]); buf_ld2(rI2, vxc, ro, pa[1], pb[1]);
             ro = img_row_off(yy0);
-            cl[0] = buf_ld(rI1, vxl, ro); buf_ld2(rI1, vxc, ro, ca[0], cb[0]);
-            cl[1] = buf_ld(rI2, vxl, ro); buf_ld2(rI2, vxc, ro, ca[1], cb[1]);
+            buf_ld2(rI1, vxc, ro, ca[0], cb[0]); buf_ld2(rI2, vxc, ro, ca[1], cb[1]);
+            pl[0] = left_tap(pb[0]); pl[1] = left_tap(pb[1]);
+            cl[0] = left_tap(cb[0]); cl[1] = left_tap(cb[1]);
         }
-        double ql[PF][2], qa[PF][2], qb[PF][2];              // queue slot of marched row i = i % PF
+        double qa[PF][2], qb[PF][2];                        // queue slot of marched row i = i % PF
 #pragma unroll
         for (int r = 1; r < PF; ++r) {
             const int o = img_row_off(yy0 + r);
-            ql[r][0] = buf_ld(rI1, vxl, o); buf_ld2(rI1, vxc, o, qa[r][0], qb[r][0]);
-            ql[r][1] = buf_ld(rI2, vxl, o); buf_ld2(rI2, vxc, o, qa[r][1], qb[r][1]);
+            buf_ld2(rI1, vxc, o, qa[r][0], qb[r][0]);
+            buf_ld2(rI2, vxc, o, qa[r][1], qb[r][1]);
         }
-        ql[0][0] = ql[0][1] = qa[0][0] = qa[0][1] = qb[0][0] = qb[0][1] = 0.0;
+        qa[0][0] = qa[0][1] = qb[0][0] = qb[0][1] = 0.0;
 
-        auto fstep = [&](auto uc, int it) __attribute__((always_inline)) {
-            constexpr int U = decltype(uc)::value;
-            constexpr int PAR = U & 1;
-            SP_STAMP(t0);
-            {                                               // prefetch image row it + PF into the slot freed by the last rotate
-                const int rn = img_row_off(yy0 + it + PF);
-                ql[U % PF][0] = buf_ld(rI1, vxl, rn); buf_ld2(rI1, vxc, rn, qa[U % PF][0], qb[U % PF][0]);
-                ql[U % PF][1] = buf_ld(rI2, vxl, rn); buf_ld2(rI2, vxc, rn, qa[U % PF][1], qb[U % PF][1]);
+        // one marched row i (queue slot QS = i % PF, static): prefetch row i + PF into the slot the last rotate
+        // freed, products of row i -> LDS plane (SP, E), rotate row i + 1 in
+        auto frow = [&](auto spc, auto ec, int i) __attribute__((always_inline)) {
+            constexpr int SP = decltype(spc)::value, E = decltype(ec)::value;
+            constexpr int QS = (2 * SP + E) % PF;
+            {
+                const int rn = img_row_off(yy0 + i + PF);
+                buf_ld2(rI1, vxc, rn, qa[QS][0], qb[QS][0]);
+                buf_ld2(rI2, vxc, rn, qa[QS][1], qb[QS][1]);
             }
-            const int yy = yy0 + it;
-            const bool keep = yy >= 0 && yy < H && col_in;
+            const int yy = yy0 + i;
+            const bool row_in = yy >= 0 && yy < H;
             double fxa = f2d_x(pl[0], pa[0], cl[0], ca[0]) + f2d_x(pl[1], pa[1], cl[1], ca[1]);
             double fya = f2d_y(pl[0], pa[0], cl[0], ca[0]) + f2d_y(pl[1], pa[1], cl[1], ca[1]);
             const double fta = f2d_neg(pl[0], pa[0], cl[0], ca[0]) + f2d_pos(pl[1], pa[1], cl[1], ca[1]);
             double fxb = f2d_x(pa[0], pb[0], ca[0], cb[0]) + f2d_x(pa[1], pb[1], ca[1], cb[1]);
             double fyb = f2d_y(pa[0], pb[0], ca[0], cb[0]) + f2d_y(pa[1], pb[1], ca[1], cb[1]);
             const double ftb = f2d_neg(pa[0], pb[0], ca[0], cb[0]) + f2d_pos(pa[1], pb[1], ca[1], cb[1]);
-            fxa = keep ? fxa : 0.0; fya = keep ? fya : 0.0;
-            fxb = keep ? fxb : 0.0; fyb = keep ? fyb : 0.0;
+            if (!(row_in && all_col_in)) {                  // rows / columns outside the image contribute 0 (wave-uniform test)
+                const bool keep = row_in && col_in;
+                fxa = keep ? fxa : 0.0; fya = keep ? fya : 0.0;
+                fxb = keep ? fxb : 0.0; fyb = keep ? fyb : 0.0;
+            }
             lk_d2 o;
-            o.x = fxa * fxa; o.y = fxb * fxb; *reinterpret_cast<lk_d2 *>(&s_prod[PAR][0][2 * p_chunk]) = o;
-            o.x = fya * fya; o.y = fyb * fyb; *reinterpret_cast<lk_d2 *>(&s_prod[PAR][1][2 * p_chunk]) = o;
-            o.x = fxa * fya; o.y = fxb * fyb; *reinterpret_cast<lk_d2 *>(&s_prod[PAR][2][2 * p_chunk]) = o;
-            o.x = fxa * fta; o.y = fxb * ftb; *reinterpret_cast<lk_d2 *>(&s_prod[PAR][3][2 * p_chunk]) = o;
-            o.x = fya * fta; o.y = fyb * ftb; *reinterpret_cast<lk_d2 *>(&s_prod[PAR][4][2 * p_chunk]) = o;
-            SP_STAMP(t1);
+            o.x = fxa * fxa; o.y = fxb * fxb; *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][0][2 * p_chunk]) = o;
+            o.x = fya * fya; o.y = fyb * fyb; *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][1][2 * p_chunk]) = o;
+            o.x = fxa * fya; o.y = fxb * fyb; *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][2][2 * p_chunk]) = o;
+            o.x = fxa * fta; o.y = fxb * ftb; *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][3][2 * p_chunk]) = o;
+            o.x = fya * fta; o.y = fyb * ftb; *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][4][2 * p_chunk]) = o;
             // rotate: the only wait for the prefetch
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 pl[g] = cl[g]; pa[g] = ca[g]; pb[g] = cb[g];
-                cl[g] = ql[(U + 1) % PF][g]; ca[g] = qa[(U + 1) % PF][g]; cb[g] = qb[(U + 1) % PF][g];
+                ca[g] = qa[(QS + 1) % PF][g]; cb[g] = qb[(QS + 1) % PF][g];
+                cl[g] = left_tap(cb[g]);
             }
+        };
+        auto fstep = [&](auto spc, int st) __attribute__((always_inline)) {
+            SP_STAMP(t0);
+            frow(spc, std::integral_constant<int, 0>{}, 2 * st);
+            frow(spc, std::integral_constant<int, 1>{}, 2 * st + 1);
 #ifdef LK_SPLIT_STAMPS
             asm volatile("" :: "v"(cl[0]), "v"(ca[0]), "v"(cb[0]), "v"(cl[1]), "v"(ca[1]), "v"(cb[1]));
 #endif
-            SP_STAMP(t2);
+            SP_STAMP(t1);
             __syncthreads();
-            SP_STAMP(t3);
-            SP_ACC(0, t0, t1); SP_ACC(2, t1, t2); SP_ACC(3, t2, t3);
+            SP_STAMP(t2);
+            SP_ACC(0, t0, t1); SP_ACC(3, t1, t2);
         };
-        for (int base = 0; base < nit; base += UN) {         // nit is a multiple of UN: no guards inside a group
-            [&]<int... Us>(std::integer_sequence<int, Us...>) __attribute__((always_inline)) {
-                (fstep(std::integral_constant<int, Us>{}, base + Us), ...);
-            }(std::make_integer_sequence<int, UN>{});
+        for (int st = 0; st < NS; st += 2) {                 // NS is even: no guards inside a group
+            fstep(std::integral_constant<int, 0>{}, st);
+            fstep(std::integral_constant<int, 1>{}, st + 1);
         }
     } else if (wv < C::NB) {
         // =========================================================================================
@@ -227,7 +246,6 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         const bool fix_x = is_out && inner_x && clipped_x;      // lanes whose window is clipped horizontally (first / last block)
         const bool any_fix_x = __builtin_amdgcn_ballot_w64(fix_x) != 0;
         const int s_slot = KH == 1 ? t : 2 * (((t % K) >> 1) * C::SSTR + t / K) + (t & 1);
-        const int nrows = y1 - y0;
 
         [[maybe_unused]] UpSel1 us{};
         [[maybe_unused]] double hu[3] = {0, 0, 0}, hv[3] = {0, 0, 0};   // carried coarse rows (rotated every even row)
@@ -269,26 +287,22 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         const int vxo = x * 8;
         int sou = 0, sov = 0;                                   // byte offsets of output row r in the u / v strips
 
-        // One output row r = y - y0 (< nrows) at static position U of the unrolled group (y0 is even: row parity =
-        // U & 1 = parity of the pipeline step = LDS buffer; tap buffer = (U >> 1) & 1).  FAST: the window is
-        // vertically inside the image, so nothing but the per-lane column masks is conditional.  Both variants
-        // issue the same vector-memory instructions, unconditionally (see the file header).
+        // One step = the output row pair (y, y + 1), y = y0 + 2p even, at static pair parity P2 = p & 1 (tap
+        // buffer; LDS step parity = (p + R) & 1).  FAST: both windows are vertically inside the image, so nothing
+        // but the per-lane column masks is conditional.  Both variants issue the same vector-memory instructions,
+        // unconditionally (see the file header); the two solves are independent and interleave.
         const int vo_lane = is_out ? vxo : (int)0x80000000;   // out of range: the store is dropped
-        auto brow = [&](auto uc, auto fastc, int r) __attribute__((always_inline)) {
-            constexpr int U = decltype(uc)::value;
+        auto solve5 = [&](const double (&S)[5], bool inner, double &u, double &v) __attribute__((always_inline)) {
+            const double det = S[0] * S[1] - S[2] * S[2];
+            const double un = S[2] * S[4] - S[1] * S[3];
+            const double vn = S[3] * S[2] - S[0] * S[4];
+            const bool nz = det != 0.0 && inner;            // cv::divide: x/0 -> 0; outermost ring: 0
+            const double qu = un / det, qv = vn / det;
+            u = nz ? qu : 0.0;
+            v = nz ? qv : 0.0;
+        };
+        auto solve_row = [&](auto fastc, int y, const double (&S)[5], double &u, double &v) __attribute__((always_inline)) {
             constexpr bool FAST = decltype(fastc)::value;
-            constexpr int PAR = U & 1;
-            constexpr int TB = (U >> 1) & 1;
-            const int y = y0 + r;
-            if constexpr (HAS_UP && PAR == 1) {             // taps consumed by the NEXT odd row (y + 2)
-                int su, sv;
-                tap_off(y, su, sv);
-                tp[TB ^ 1][0] = buf_ld(rCU, us.jm, su); tp[TB ^ 1][1] = buf_ld(rCU, us.jc, su); tp[TB ^ 1][2] = buf_ld(rCU, us.jp, su);
-                tp[TB ^ 1][3] = buf_ld(rCV, us.jm, sv); tp[TB ^ 1][4] = buf_ld(rCV, us.jc, sv); tp[TB ^ 1][5] = buf_ld(rCV, us.jp, sv);
-            }
-            double S[5];
-#pragma unroll
-            for (int f = 0; f < 5; ++f) S[f] = s_sums[PAR][f][s_slot];
             bool inner, fix;
             if constexpr (FAST) {
                 inner = inner_x;
@@ -297,60 +311,68 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                 inner = y >= 1 && y <= H - 2 && inner_x;
                 fix = is_out && inner && ((y - R < 0) || (y + R > H - 1) || clipped_x);
             }
-            if (fix) {                                      // SerialPyr.cpp:94-95: partial window -> m(y,x) * WIN^2
+            solve5(S, inner, u, v);
+            if (fix) {                                      // SerialPyr.cpp:94-95: partial window -> m(y,x) * WIN^2 (rare lanes: redone)
                 double pc[5];
                 lk_products_at(a.i1.at(pair), a.i2.at(pair), a.i1.pitch, H, W, y, x, pc);
 #pragma unroll
-                for (int f = 0; f < 5; ++f) S[f] = pc[f] * (double)(WIN * WIN);
+                for (int f = 0; f < 5; ++f) pc[f] = pc[f] * (double)(WIN * WIN);
+                solve5(pc, inner, u, v);
             }
-            const double det = S[0] * S[1] - S[2] * S[2];
-            const double un = S[2] * S[4] - S[1] * S[3];
-            const double vn = S[3] * S[2] - S[0] * S[4];
-            const bool nz = det != 0.0 && inner;            // cv::divide: x/0 -> 0; outermost ring: 0
-            const double qu = un / det, qv = vn / det;
-            double u = nz ? qu : 0.0;
-            double v = nz ? qv : 0.0;
+        };
+        auto bpair = [&](auto pc2, auto fastc, int p) __attribute__((always_inline)) {
+            constexpr int P2 = decltype(pc2)::value;
+            constexpr int SPB = (P2 + R) & 1;
+            const int y = y0 + 2 * p;
+            if constexpr (HAS_UP) {                         // taps consumed by the NEXT pair's odd row (y + 3)
+                int su, sv;
+                tap_off(y + 1, su, sv);
+                tp[P2 ^ 1][0] = buf_ld(rCU, us.jm, su); tp[P2 ^ 1][1] = buf_ld(rCU, us.jc, su); tp[P2 ^ 1][2] = buf_ld(rCU, us.jp, su);
+                tp[P2 ^ 1][3] = buf_ld(rCV, us.jm, sv); tp[P2 ^ 1][4] = buf_ld(rCV, us.jc, sv); tp[P2 ^ 1][5] = buf_ld(rCV, us.jp, sv);
+            }
+            double S0[5], S1[5];
+#pragma unroll
+            for (int f = 0; f < 5; ++f) { S0[f] = s_sums[SPB][0][f][s_slot]; S1[f] = s_sums[SPB][1][f][s_slot]; }
+            double ue, ve, uo, vo;
+            solve_row(fastc, y, S0, ue, ve);
+            solve_row(fastc, y + 1, S1, uo, vo);
             if constexpr (HAS_UP) {
-                if constexpr (PAR == 0) {                   // rotate in the coarse row turned into slot 0 last row
+                {                                           // even row: rotate in the coarse row turned into slot 0 last pair
                     const double nu = hu[0], nv = hv[0];
                     hu[0] = hu[1]; hu[1] = hu[2]; hu[2] = nu;
                     hv[0] = hv[1]; hv[1] = hv[2]; hv[2] = nv;
-                    u += (hu[0] + hu[1] * 6 + hu[2]) * (1.0 / 64);
-                    v += (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);
-                } else {
-                    u += ((hu[1] + hu[2]) * 4) * (1.0 / 64);
-                    v += ((hv[1] + hv[2]) * 4) * (1.0 / 64);
-                    hu[0] = pyrup_h1v(tp[TB][0], tp[TB][1], tp[TB][2], us);   // next coarse row, used from row y+1 on
-                    hv[0] = pyrup_h1v(tp[TB][3], tp[TB][4], tp[TB][5], us);
+                    ue += (hu[0] + hu[1] * 6 + hu[2]) * (1.0 / 64);
+                    ve += (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);
                 }
+                uo += ((hu[1] + hu[2]) * 4) * (1.0 / 64);
+                vo += ((hv[1] + hv[2]) * 4) * (1.0 / 64);
+                hu[0] = pyrup_h1v(tp[P2][0], tp[P2][1], tp[P2][2], us);   // next coarse row, used from the next pair on
+                hv[0] = pyrup_h1v(tp[P2][3], tp[P2][4], tp[P2][5], us);
             }
-            buf_st(rU, vo_lane, sou, u);
-            buf_st(rV, vo_lane, sov, v);
-            sou += upb; sov += vpb;
+            buf_st(rU, vo_lane, sou, ue);
+            buf_st(rV, vo_lane, sov, ve);
+            buf_st(rU, vo_lane, sou + upb, uo);
+            buf_st(rV, vo_lane, sov + vpb, vo);
+            sou += 2 * upb; sov += 2 * vpb;
         };
-        auto bstep = [&](auto uc, int r) __attribute__((always_inline)) {
+        auto bstep = [&](auto pc2, int p) __attribute__((always_inline)) {
             SP_STAMP(t0);
-            if (H > 2 * R && (unsigned)(y0 + r - R) <= (unsigned)(H - 1 - 2 * R)) brow(uc, std::true_type{}, r);
-            else brow(uc, std::false_type{}, r);
+            if (H >= 2 * R + 2 && (unsigned)(y0 + 2 * p - R) <= (unsigned)(H - 2 - 2 * R)) bpair(pc2, std::true_type{}, p);
+            else bpair(pc2, std::false_type{}, p);
             SP_STAMP(t1);
             __syncthreads();
             SP_STAMP(t2);
             SP_ACC(1, t0, t1); SP_ACC(3, t1, t2);
         };
-        for (int k = 0; k < 2 * R + 2; ++k) __syncthreads();   // pipeline fill: no window sums yet
-        int r = 0;
-        for (; r + 4 <= nrows; r += 4) {                        // whole groups
-            bstep(std::integral_constant<int, 0>{}, r);
-            bstep(std::integral_constant<int, 1>{}, r + 1);
-            bstep(std::integral_constant<int, 2>{}, r + 2);
-            bstep(std::integral_constant<int, 3>{}, r + 3);
+        for (int k = 0; k < R + 2; ++k) __syncthreads();       // pipeline fill: no window sums yet
+        const int npairs = nrows / 2;
+        int p = 0;
+        for (; p + 2 <= npairs; p += 2) {                       // whole groups
+            bstep(std::integral_constant<int, 0>{}, p);
+            bstep(std::integral_constant<int, 1>{}, p + 1);
         }
-        if (r < nrows) {                                        // nrows is even: a last half group, then two idle steps
-            bstep(std::integral_constant<int, 0>{}, r);
-            bstep(std::integral_constant<int, 1>{}, r + 1);
-            __syncthreads();
-            __syncthreads();
-        }
+        if (p < npairs) bstep(std::integral_constant<int, 0>{}, p);
+        for (int k = ns; k < NS; ++k) __syncthreads();          // idle tail step
     } else {
         // =========================================================================================
         // S waves: one field each, K adjacent columns per lane
@@ -367,10 +389,9 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 #pragma unroll
         for (int c = 0; c < K; ++c) pre[c] = 0.0;
 
-        auto srow = [&](auto kc, int i) __attribute__((always_inline)) {
-            constexpr int KC = decltype(kc)::value;
-            SP_STAMP(t0);
-            const double *pp = &s_prod[i & 1][f][0];
+        auto srow = [&](auto kc, auto ec, int i) __attribute__((always_inline)) {
+            constexpr int KC = decltype(kc)::value, E = decltype(ec)::value;
+            const double *pp = &s_prod[(i >> 1) & 1][E][f][0];
             double v[NV];
 #pragma unroll
             for (int d = -PADJ; d <= PADJ; ++d)
@@ -404,11 +425,6 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                     hs[c] = s;
                 }
             }
-#ifdef LK_SPLIT_STAMPS
-#pragma unroll
-            for (int c = 0; c < K; ++c) asm volatile("" :: "v"(hs[c]));
-#endif
-            SP_STAMP(t1);
             // vertical van Herk / Gil-Werman step at static chunk position KC
             double S[K];
 #pragma unroll
@@ -424,31 +440,45 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                     for (int c = 0; c < K; ++c) ring[q][c] += ring[q + 1][c];
             }
             if (i >= 2 * R) {                                // a full vertical window: hand the K sums to the back end
-                double *sp = &s_sums[i & 1][f][0];
+                double *sp = &s_sums[(i >> 1) & 1][E][f][0];
 #pragma unroll
                 for (int h = 0; h < KH; ++h) {
                     lk_d2 o; o.x = S[2 * h]; o.y = S[2 * h + 1];
                     *reinterpret_cast<lk_d2 *>(sp + 2 * (h * C::SSTR + j)) = o;
                 }
             }
-            SP_STAMP(t2);
+        };
+        // one step = marched rows i, i + 1 at static chunk positions Q % WIN, (Q + 1) % WIN
+        auto sstep = [&](auto qc, int i) __attribute__((always_inline)) {
+            constexpr int Q = decltype(qc)::value;
+            SP_STAMP(t0);
+            srow(std::integral_constant<int, Q % WIN>{}, std::integral_constant<int, 0>{}, i);
+            srow(std::integral_constant<int, (Q + 1) % WIN>{}, std::integral_constant<int, 1>{}, i + 1);
+            SP_STAMP(t1);
             __syncthreads();
-            SP_STAMP(t3);
-            SP_ACC(0, t0, t1); SP_ACC(1, t1, t2); SP_ACC(3, t2, t3);
+            SP_STAMP(t2);
+            SP_ACC(0, t0, t1); SP_ACC(3, t1, t2);
         };
         __syncthreads();                                     // pipeline step 0: only the front end works
-        for (int base = 0; base < nm; base += WIN) {
-            [&]<int... Ks>(std::integer_sequence<int, Ks...>) __attribute__((always_inline)) {
-                ((base + Ks < nm ? (srow(std::integral_constant<int, Ks>{}, base + Ks), 0) : 0), ...);
+        // The van Herk chunks are anchored to ABSOLUTE image rows (chunk position of image row r = r mod WIN), so the
+        // order in which a window's rows are added belongs to the output row, not to the strip: results do not depend
+        // on the strip height the launcher picks from the batch size (sharded == unsharded bit for bit).
+        // The unrolled body holds WIN steps; step Qs works at chunk positions (2Qs % WIN, (2Qs + 1) % WIN), which visit
+        // every residue (WIN is odd), so the march enters the body at the step whose first row has position kc0.
+        const int kc0 = ((yy0 % WIN) + WIN) % WIN;           // chunk position of marched row 0
+        const int qs0 = (kc0 & 1) ? (kc0 + WIN) / 2 : kc0 / 2;
+        for (int base = 0; base < qs0 + nsw; base += WIN) {
+            [&]<int... Qs>(std::integer_sequence<int, Qs...>) __attribute__((always_inline)) {
+                ((base + Qs >= qs0 && base + Qs < qs0 + nsw ? (sstep(std::integral_constant<int, 2 * Qs>{}, 2 * (base + Qs - qs0)), 0) : 0), ...);
             }(std::make_integer_sequence<int, WIN>{});
         }
-        for (int k = nm + 1; k < nit; ++k) __syncthreads(); // pipeline steps nm + 1 ..: only the back end works / idle tail
+        for (int k = nsw + 1; k < NS; ++k) __syncthreads(); // remaining steps: only the back end works / idle tail
     }
 #ifdef LK_SPLIT_STAMPS
     if (a.dbg && (threadIdx.x & 63) == 0) {
         const unsigned wid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * C::NW + wv;
         for (int k = 0; k < 6; ++k) a.dbg[wid * 8 + k] = seg[k];
-        a.dbg[wid * 8 + 6] = nit;
+        a.dbg[wid * 8 + 6] = NS;
         a.dbg[wid * 8 + 7] = wv;
     }
 #endif

@@ -61,13 +61,11 @@ __global__ __launch_bounds__(64, 2) void lk_w3x2_kernel(LKArgs a)
     const int nmarch = (y1 - y0) + 2 * R;
     const int yy0 = y0 - R;
 
-    double ringA[WIN][5], ringB[WIN][5], preA[5], preB[5];
+    double ringA[WIN][5], ringB[WIN][5];       // the last three rows' horizontal sums (slot = marched row mod 3)
 #pragma unroll
     for (int q = 0; q < WIN; ++q)
 #pragma unroll
         for (int f = 0; f < 5; ++f) ringA[q][f] = ringB[q][f] = 0.0;
-#pragma unroll
-    for (int f = 0; f < 5; ++f) preA[f] = preB[f] = 0.0;
 
     auto img_row_off = [&](int yy) {
         int rr = yy < 0 ? -yy : yy;
@@ -164,15 +162,11 @@ __global__ __launch_bounds__(64, 2) void lk_w3x2_kernel(LKArgs a)
         for (int f = 0; f < 5; ++f) {
             const double hA = (dpp_wave_shr1(pB[f]) + pA[f]) + pB[f];   // (left + centre) + right
             const double hB = (pA[f] + pB[f]) + dpp_wave_shl1(pA[f]);
-            preA[f] = (K == 0) ? hA : preA[f] + hA;
-            preB[f] = (K == 0) ? hB : preB[f] + hB;
-            SA[f] = (K < WIN - 1) ? ringA[(K + 1) % WIN][f] + preA[f] : preA[f];
-            SB[f] = (K < WIN - 1) ? ringB[(K + 1) % WIN][f] + preB[f] : preB[f];
-            if (K > 0) { ringA[K][f] = hA; ringB[K][f] = hB; }
-        }
-        if (K == WIN - 1) {
-#pragma unroll
-            for (int f = 0; f < 5; ++f) { ringA[1][f] += ringA[2][f]; ringB[1][f] += ringB[2][f]; }
+            // three rows, summed directly in one fixed order, (row i-2 + row i-1) + row i: independent of where the
+            // strip starts, so a sharded / differently batched run reproduces the same bits
+            SA[f] = (ringA[(K + 1) % 3][f] + ringA[(K + 2) % 3][f]) + hA;
+            SB[f] = (ringB[(K + 1) % 3][f] + ringB[(K + 2) % 3][f]) + hB;
+            ringA[K][f] = hA; ringB[K][f] = hB;
         }
         // rotate: the only wait for the row prefetched PF iterations ago
         p1a = c1a; p1b = c1b; p2a = c2a; p2b = c2b; lp1 = lc1; lp2 = lc2;

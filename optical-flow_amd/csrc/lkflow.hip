@@ -67,9 +67,15 @@ struct lkflow_ctx {
     std::vector<long long> off_flow;  // level >= 1: u planes [pairs] then v planes [pairs]
     // resident blocks per CU of each kernel instantiation ON THIS DEVICE (occupancy query, first use)
     std::unordered_map<const void *, int> occ;
-    // host-API staging (prev, next, U, V contiguous planes)
+    // host-API staging (prev, next, U, V contiguous planes [+ two uint8 planes])
     double *stage = nullptr;
     size_t stage_bytes = 0;
+    bool host_inflight = false;        // an enqueued host-buffer pair has not been waited for yet
+    // opt-in (LKFLOW_OPT_PIN_HOST): caller buffers page-locked in place, so that the host <-> device copies are
+    // true asynchronous DMA; kept until the context is destroyed or the option is switched off
+    int pin_host = 0;
+    struct Pin { char *p; size_t n; };
+    std::vector<Pin> pins;
 };
 
 namespace {
@@ -86,19 +92,28 @@ bool hip_ok(lkflow_ctx *ctx, hipError_t e, const char *what)
     } while (0)
 
 // ---- optional per-launch HIP-event bracketing (LKFLOW_OPT_PROFILE) ------------------------------
-hipEvent_t ev_get(lkflow_ctx *ctx)
+constexpr size_t MAX_PROFILE_RECS = 1u << 16;   // launches bracketed between two profile reads; further ones go untimed
+
+hipEvent_t ev_get(lkflow_ctx *ctx)                // nullptr: no event could be created (the launch then goes untimed)
 {
     if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
 struct ProfScope {
     lkflow_ctx *ctx; hipStream_t s; bool on; hipEvent_t a = nullptr, b = nullptr; int slot;
     ProfScope(lkflow_ctx *c, int stage, int level, hipStream_t st) : ctx(c), s(st), slot(stage * LKFLOW_MAX_LEVELS + level)
     {
-        on = c->profile == -1 || c->profile == 1 + slot;
-        if (on) { a = ev_get(c); b = ev_get(c); (void)hipEventRecord(a, s); }
+        on = (c->profile == -1 || c->profile == 1 + slot) && c->recs.size() < MAX_PROFILE_RECS;
+        if (on) {
+            a = ev_get(c); b = ev_get(c);
+            if (!a || !b) {                                  // event creation failed: give back what exists, do not time
+                if (a) c->ev_pool.push_back(a);
+                if (b) c->ev_pool.push_back(b);
+                a = b = nullptr; on = false;
+            } else (void)hipEventRecord(a, s);
+        }
     }
     ~ProfScope()
     {
@@ -266,7 +281,7 @@ template <int WIN, int K>
 int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
 {
     using C = lk::SplitCfg<WIN, K>;
-    if ((a.W & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return -1;   // odd / tiny levels: one-role kernel
+    if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return -1;   // odd / tiny levels: one-role kernel
     const int gx = (a.W + C::XO - 1) / C::XO;
     int th = ctx->tile_rows;
     if (th <= 0) {
@@ -303,6 +318,14 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
     if (has_up) hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true>), grid, dim3(C::NT), 0, s, a);
     else hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, false>), grid, dim3(C::NT), 0, s, a);
     return LKFLOW_OK;
+}
+
+// shapes the wave-specialised kernel takes (the rest -- odd or tiny levels -- runs the one-role kernel)
+bool split_applies(int win, int W, int H)
+{
+    static const int split = getenv("LKFLOW_SPLIT") ? atoi(getenv("LKFLOW_SPLIT")) : 1;   // debug knob (A/B): 0 = one-role kernel
+    const int R = win / 2;
+    return split && win >= 5 && win <= LKFLOW_MAX_WIN && !(W & 1) && !(H & 1) && W >= 2 && H > R + LK_SPLIT_PF + 1;
 }
 
 // -1: this window has no wave-specialised instantiation
@@ -413,8 +436,7 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
         if (win == 3 && !no_x2 && a.W >= 2 && !(a.W & 1)) rc = launch_w3x2(ctx, a, has_up, pairs, s);   // 2 columns per lane
         else if (win == 3 && !no_w3) rc = launch_lk3_win<3, 64>(ctx, a, has_up, pairs, s);   // barrier-free DPP kernel
         else {
-            static const int split = getenv("LKFLOW_SPLIT") ? atoi(getenv("LKFLOW_SPLIT")) : 1;   // debug knob (A/B): 0 = one-role kernel
-            rc = (split && win >= 5) ? launch_split(ctx, a, has_up, pairs, win, s) : -1;
+            rc = split_applies(win, a.W, a.H) ? launch_split(ctx, a, has_up, pairs, win, s) : -1;
             if (rc == -1)
                 rc = use128 ? launch_lk3<128>(ctx, a, has_up, pairs, win, s) : launch_lk3<256>(ctx, a, has_up, pairs, win, s);
         }
@@ -498,6 +520,27 @@ const char *lkflow_strerror(int status)
 const char *lkflow_last_error(const lkflow_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 const char *lkflow_version(void) { return LKFLOW_VERSION_STR; }
 
+int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok, char *buf, size_t n)
+{
+    if (!buf || n == 0 || rows < 1 || cols < 1) return LKFLOW_E_ARG;
+    int rc = check_win(win);
+    if (rc) return rc;
+    const char *up = has_up ? "true" : "false";
+    static const bool no_fused = getenv("LKFLOW_NO_W3_FUSED") != nullptr || getenv("LKFLOW_NO_W3X2") != nullptr;
+    static const bool no_x2 = getenv("LKFLOW_NO_W3X2") != nullptr, no_w3 = getenv("LKFLOW_NO_W3_DPP") != nullptr;
+    if (win == 3 && has_up && fused_ok && !no_fused && cols >= 2 && !(cols & 1) && !(rows & 1)) snprintf(buf, n, "lk::lk_w3x2f_kernel");
+    else if (win == 3 && !no_x2 && cols >= 2 && !(cols & 1)) snprintf(buf, n, "lk::lk_w3x2_kernel<%s>", up);
+    else if (win == 3 && !no_w3) snprintf(buf, n, "lk::lk_march3_kernel<3, 64, %s>", up);
+    else if (split_applies(win, cols, rows)) snprintf(buf, n, "lk::lk_split_kernel<%d, 2, %s>", win, up);
+    else {
+        const int R = win / 2;
+        const long long c128 = (long long)((cols + (128 - 2 * R) - 1) / (128 - 2 * R)) * 128;
+        const long long c256 = (long long)((cols + (256 - 2 * R) - 1) / (256 - 2 * R)) * 256;
+        snprintf(buf, n, "lk::lk_march3_kernel<%d, %d, %s>", win, (win <= 15 && c128 * 100 <= c256 * 108) ? 128 : 256, up);
+    }
+    return LKFLOW_OK;
+}
+
 int lkflow_ctx_create(lkflow_ctx **out, int device)
 {
     if (!out) return LKFLOW_E_ARG;
@@ -527,6 +570,7 @@ void lkflow_ctx_destroy(lkflow_ctx *ctx)
     (void)hipDeviceSynchronize();
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->stage) (void)hipFree(ctx->stage);
+    for (auto &q : ctx->pins) (void)hipHostUnregister(q.p);
     for (auto &r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -549,6 +593,17 @@ int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value)
             if (value < -1 || value > LKFLOW_N_STAGES * LKFLOW_MAX_LEVELS) return LKFLOW_E_ARG;
             ctx->profile = value;
             return LKFLOW_OK;
+        case LKFLOW_OPT_PIN_HOST:
+            if (value < 0 || value > 1) return LKFLOW_E_ARG;
+            if (!value && ctx->pin_host) {
+                if (set_device(ctx)) return LKFLOW_E_HIP;
+                (void)hipStreamSynchronize(ctx->own_stream);
+                ctx->host_inflight = false;
+                for (auto &q : ctx->pins) (void)hipHostUnregister(q.p);
+                ctx->pins.clear();
+            }
+            ctx->pin_host = value;
+            return LKFLOW_OK;
         default: return LKFLOW_E_ARG;
     }
 }
@@ -561,17 +616,20 @@ int lkflow_ctx_profile_read(lkflow_ctx *ctx, double *total_ms, int *n_launches)
     for (int i = 0; i < LKFLOW_N_STAGES * LKFLOW_MAX_LEVELS; ++i) { total_ms[i] = 0.0; n_launches[i] = 0; }
     int rc = set_device(ctx);
     if (rc) return rc;
-    for (auto &r : ctx->recs) {
-        HIP_TRY(ctx, hipEventSynchronize(r.b));
+    std::vector<lkflow_ctx::Rec> recs;
+    recs.swap(ctx->recs);                       // every record leaves the list exactly once, whatever happens below
+    int status = LKFLOW_OK;
+    for (auto &r : recs) {
         float ms = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, r.a, r.b));
-        total_ms[r.slot] += ms;
-        n_launches[r.slot] += 1;
+        if (status == LKFLOW_OK &&
+            (!hip_ok(ctx, hipEventSynchronize(r.b), "hipEventSynchronize") ||
+             !hip_ok(ctx, hipEventElapsedTime(&ms, r.a, r.b), "hipEventElapsedTime")))
+            status = LKFLOW_E_HIP;
+        if (status == LKFLOW_OK) { total_ms[r.slot] += ms; n_launches[r.slot] += 1; }
         ctx->ev_pool.push_back(r.a);
         ctx->ev_pool.push_back(r.b);
     }
-    ctx->recs.clear();
-    return LKFLOW_OK;
+    return status;
 }
 
 int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int n_pairs)
@@ -734,35 +792,104 @@ static int ensure_stage(lkflow_ctx *ctx, size_t bytes)
     return LKFLOW_OK;
 }
 
-int lkflow_compute_f64(lkflow_ctx *ctx, double *prev, double *next, int rows, int cols,
-                       size_t step_bytes, double *U, double *V, size_t uv_step_bytes, int pyr_levels,
-                       int win, unsigned flags)
+// LKFLOW_OPT_PIN_HOST: page-lock [p, p + n) once (kept in the context); failure is not an error -- the copy then
+// takes the runtime's pageable path, as without the option.
+static void pin_host_range(lkflow_ctx *ctx, const void *ptr, size_t n)
+{
+    if (!ctx->pin_host || !ptr || !n) return;
+    char *p = (char *)const_cast<void *>(ptr);
+    for (auto &q : ctx->pins)
+        if (p >= q.p && p + n <= q.p + q.n) return;
+    if (ctx->pins.size() >= 16) {                            // oldest out
+        (void)hipHostUnregister(ctx->pins.front().p);
+        ctx->pins.erase(ctx->pins.begin());
+    }
+    if (hipHostRegister(p, n, hipHostRegisterDefault) == hipSuccess) ctx->pins.push_back({p, n});
+    else (void)hipGetLastError();
+}
+
+// H2D (+ convertTo on the device for 8-bit frames), the pyramid, D2H: all enqueued on the context's own stream.
+static int enqueue_host_pair(lkflow_ctx *ctx, const void *prev, const void *next, bool u8, int rows, int cols,
+                             size_t step_bytes, double *U, double *V, size_t uv_step_bytes, int pyr_levels, int win,
+                             unsigned flags)
 {
     if (!ctx || !prev || !next || !U || !V) return LKFLOW_E_ARG;
-    int rc = check_common(rows, cols, step_bytes, uv_step_bytes, 1);
+    const size_t esz = u8 ? 1 : 8;
+    if (rows < 1 || cols < 1 || step_bytes < (size_t)cols * esz || step_bytes % esz) return LKFLOW_E_ARG;
+    int rc = check_common(rows, cols, (size_t)cols * 8, uv_step_bytes, 1);
     if (rc) return rc;
+    if (!u8 && (rc = check_common(rows, cols, step_bytes, uv_step_bytes, 1))) return rc;
     if (flags & ~LKFLOW_MUTATE_INPUTS) return LKFLOW_E_ARG;
+    if (u8 && flags) return LKFLOW_E_ARG;                    // 8-bit frames cannot hold the warped CV_64F images
     if (pyr_levels < 1 || pyr_levels > max_levels(cols, rows)) return LKFLOW_E_LEVELS;
     if ((rc = check_win(win))) return rc;
     if ((rc = set_device(ctx))) return rc;
-    const size_t row_b = (size_t)cols * 8, plane_b = row_b * rows;
-    if ((rc = ensure_stage(ctx, 4 * plane_b))) return rc;
-    double *d_prev = ctx->stage, *d_next = d_prev + (size_t)rows * cols, *d_u = d_next + (size_t)rows * cols,
-           *d_v = d_u + (size_t)rows * cols;
     hipStream_t s = ctx->own_stream;
-    HIP_TRY(ctx, hipMemcpy2DAsync(d_prev, row_b, prev, step_bytes, row_b, rows, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpy2DAsync(d_next, row_b, next, step_bytes, row_b, rows, hipMemcpyHostToDevice, s));
+    if (ctx->host_inflight) { HIP_TRY(ctx, hipStreamSynchronize(s)); ctx->host_inflight = false; }   // one pair per context in flight
+    const size_t npx = (size_t)rows * cols, row_b = (size_t)cols * 8, plane_b = row_b * rows;
+    if ((rc = ensure_stage(ctx, 4 * plane_b + (u8 ? 2 * npx + 64 : 0)))) return rc;
+    double *d_prev = ctx->stage, *d_next = d_prev + npx, *d_u = d_next + npx, *d_v = d_u + npx;
+    pin_host_range(ctx, prev, (size_t)(rows - 1) * step_bytes + (size_t)cols * esz);
+    pin_host_range(ctx, next, (size_t)(rows - 1) * step_bytes + (size_t)cols * esz);
+    pin_host_range(ctx, U, (size_t)(rows - 1) * uv_step_bytes + row_b);
+    pin_host_range(ctx, V, (size_t)(rows - 1) * uv_step_bytes + row_b);
+    if (u8) {
+        unsigned char *d8 = reinterpret_cast<unsigned char *>(d_v + npx);       // [prev | next], contiguous
+        HIP_TRY(ctx, hipMemcpy2DAsync(d8, cols, prev, step_bytes, cols, rows, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpy2DAsync(d8 + npx, cols, next, step_bytes, cols, rows, hipMemcpyHostToDevice, s));
+        if ((rc = lkflow_u8_to_f64_dev(ctx, d8, d_prev, 2 * npx, s))) return rc; // SerialPyr.cpp:237 on the device
+    } else {
+        HIP_TRY(ctx, hipMemcpy2DAsync(d_prev, row_b, prev, step_bytes, row_b, rows, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpy2DAsync(d_next, row_b, next, step_bytes, row_b, rows, hipMemcpyHostToDevice, s));
+    }
     rc = lkflow_compute_batch_f64_dev(ctx, d_prev, d_next, plane_b, plane_b, 1, rows, cols, row_b, d_u, d_v,
                                       plane_b, row_b, pyr_levels, win, flags, s);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpy2DAsync(U, uv_step_bytes, d_u, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpy2DAsync(V, uv_step_bytes, d_v, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
     if ((flags & LKFLOW_MUTATE_INPUTS) && pyr_levels >= 2) {
-        HIP_TRY(ctx, hipMemcpy2DAsync(prev, step_bytes, d_prev, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipMemcpy2DAsync(next, step_bytes, d_next, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpy2DAsync(const_cast<void *>(prev), step_bytes, d_prev, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpy2DAsync(const_cast<void *>(next), step_bytes, d_next, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->host_inflight = true;
     return LKFLOW_OK;
+}
+
+int lkflow_wait(lkflow_ctx *ctx)
+{
+    if (!ctx) return LKFLOW_E_ARG;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->own_stream));
+    ctx->host_inflight = false;
+    return LKFLOW_OK;
+}
+
+int lkflow_enqueue_pair_f64(lkflow_ctx *ctx, double *prev, double *next, int rows, int cols, size_t step_bytes,
+                            double *U, double *V, size_t uv_step_bytes, int pyr_levels, int win, unsigned flags)
+{
+    return enqueue_host_pair(ctx, prev, next, false, rows, cols, step_bytes, U, V, uv_step_bytes, pyr_levels, win, flags);
+}
+
+int lkflow_enqueue_pair_u8(lkflow_ctx *ctx, const unsigned char *prev, const unsigned char *next, int rows, int cols,
+                           size_t step_bytes, double *U, double *V, size_t uv_step_bytes, int pyr_levels, int win)
+{
+    return enqueue_host_pair(ctx, prev, next, true, rows, cols, step_bytes, U, V, uv_step_bytes, pyr_levels, win, 0);
+}
+
+int lkflow_compute_f64(lkflow_ctx *ctx, double *prev, double *next, int rows, int cols,
+                       size_t step_bytes, double *U, double *V, size_t uv_step_bytes, int pyr_levels,
+                       int win, unsigned flags)
+{
+    int rc = enqueue_host_pair(ctx, prev, next, false, rows, cols, step_bytes, U, V, uv_step_bytes, pyr_levels, win, flags);
+    return rc ? rc : lkflow_wait(ctx);
+}
+
+int lkflow_compute_u8(lkflow_ctx *ctx, const unsigned char *prev, const unsigned char *next, int rows, int cols,
+                      size_t step_bytes, double *U, double *V, size_t uv_step_bytes, int pyr_levels, int win)
+{
+    int rc = enqueue_host_pair(ctx, prev, next, true, rows, cols, step_bytes, U, V, uv_step_bytes, pyr_levels, win, 0);
+    return rc ? rc : lkflow_wait(ctx);
 }
 
 int lkflow_lk_f64(lkflow_ctx *ctx, const double *img1, const double *img2, int rows, int cols,
@@ -772,7 +899,7 @@ int lkflow_lk_f64(lkflow_ctx *ctx, const double *img1, const double *img2, int r
     int rc = check_common(rows, cols, step_bytes, uv_step_bytes, 1);
     if (rc) return rc;
     if ((rc = check_win(win))) return rc;
-    if ((rc = set_device(ctx))) return rc;
+    if ((rc = lkflow_wait(ctx))) return rc;                  // the staging planes may belong to an enqueued pair
     const size_t row_b = (size_t)cols * 8, plane_b = row_b * rows;
     if ((rc = ensure_stage(ctx, 4 * plane_b))) return rc;
     double *d_1 = ctx->stage, *d_2 = d_1 + (size_t)rows * cols, *d_u = d_2 + (size_t)rows * cols,

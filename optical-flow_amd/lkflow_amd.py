@@ -33,6 +33,7 @@ LKFLOW_MAX_WIN = 31
 LKFLOW_OPT_IMPL = 1
 LKFLOW_OPT_TILE_ROWS = 2
 LKFLOW_OPT_PROFILE = 3
+LKFLOW_OPT_PIN_HOST = 4
 LKFLOW_STAGE_PYRDOWN, LKFLOW_STAGE_WARP, LKFLOW_STAGE_LK = 0, 1, 2
 LKFLOW_N_STAGES, LKFLOW_MAX_LEVELS = 3, 32
 
@@ -48,6 +49,7 @@ SIGNATURES = {
     "lkflow_strerror": (ctypes.c_char_p, [_i]),
     "lkflow_last_error": (ctypes.c_char_p, [_vp]),
     "lkflow_version": (ctypes.c_char_p, []),
+    "lkflow_lk_kernel_name": (_i, [_i, _i, _i, _i, _i, ctypes.c_char_p, ctypes.c_size_t]),
     "lkflow_ctx_create": (_i, [ctypes.POINTER(_vp), _i]),
     "lkflow_ctx_destroy": (None, [_vp]),
     "lkflow_ctx_reserve": (_i, [_vp, _i, _i, _i, _i]),
@@ -55,6 +57,10 @@ SIGNATURES = {
     "lkflow_ctx_workspace_bytes": (_sz, [_vp]),
     "lkflow_ctx_profile_read": (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(_i)]),
     "lkflow_compute_f64": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp, _vp, _sz, _i, _i, _u]),
+    "lkflow_compute_u8": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp, _vp, _sz, _i, _i]),
+    "lkflow_enqueue_pair_f64": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp, _vp, _sz, _i, _i, _u]),
+    "lkflow_enqueue_pair_u8": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp, _vp, _sz, _i, _i]),
+    "lkflow_wait": (_i, [_vp]),
     "lkflow_lk_f64": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp, _vp, _sz, _i]),
     "lkflow_compute_batch_f64_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _i, _i, _sz, _vp, _vp, _sz,
                                           _sz, _i, _i, _u, _vp]),
@@ -110,6 +116,15 @@ def lib():
             fn.argtypes = args
         _LIB = L
     return _LIB
+
+
+def lk_kernel_name(rows, cols, win, has_up=True, fused_ok=True):
+    """Name (as rocprofv3 prints it) of the LK kernel the library launches for one pyramid level."""
+    buf = ctypes.create_string_buffer(128)
+    rc = lib().lkflow_lk_kernel_name(int(rows), int(cols), int(win), int(has_up), int(fused_ok), buf, 128)
+    if rc != 0:
+        raise LKFlowError(rc)
+    return buf.value.decode()
 
 
 def getMaxLayer(img_or_cols, rows=None):
@@ -218,6 +233,51 @@ class Context:
         """BASELINE.json's computeFlow(frame_prev, frame_next, U, V, pyr_levels, win): same call,
         window generalised, inputs NOT mutated."""
         return self.coarseToFineEstimation(frame_prev, frame_next, pyr_levels, win, mutate=False)
+
+    def computeFlow_u8(self, frame_prev, frame_next, pyr_levels, win=3):
+        """computeFlow for 8-bit frames (what SerialPyr.cpp:223-238 loads): convertTo(CV_64F, 1/255) runs on the
+        device, so 1 byte per pixel crosses PCIe.  Returns (U, V)."""
+        a, b = self._host_u8(frame_prev), self._host_u8(frame_next)
+        h, w = a.shape
+        u, v = np.empty((h, w)), np.empty((h, w))
+        self._chk(lib().lkflow_compute_u8(self._h, a.ctypes.data, b.ctypes.data, h, w, a.strides[0],
+                                          u.ctypes.data, v.ctypes.data, u.strides[0], int(pyr_levels), int(win)))
+        return u, v
+
+    def enqueue_pair(self, frame_prev, frame_next, pyr_levels, win=3, out=None):
+        """Asynchronous host-buffer call (lkflow_enqueue_pair_f64 / _u8 by dtype): returns the (U, V) arrays that
+        wait() completes.  The inputs must stay alive and untouched until wait()."""
+        u8 = isinstance(frame_prev, np.ndarray) and frame_prev.dtype == np.uint8
+        a = self._host_u8(frame_prev) if u8 else self._host_in(frame_prev, False)
+        b = self._host_u8(frame_next) if u8 else self._host_in(frame_next, False)
+        h, w = a.shape
+        u, v = out if out is not None else (np.empty((h, w)), np.empty((h, w)))
+        if u8:
+            rc = lib().lkflow_enqueue_pair_u8(self._h, a.ctypes.data, b.ctypes.data, h, w, a.strides[0],
+                                              u.ctypes.data, v.ctypes.data, u.strides[0], int(pyr_levels), int(win))
+        else:
+            rc = lib().lkflow_enqueue_pair_f64(self._h, a.ctypes.data, b.ctypes.data, h, w, a.strides[0],
+                                               u.ctypes.data, v.ctypes.data, u.strides[0], int(pyr_levels), int(win), 0)
+        self._chk(rc)
+        self._pending = (a, b, u, v)                  # keep the buffers alive until wait()
+        return u, v
+
+    def wait(self):
+        self._chk(lib().lkflow_wait(self._h))
+        self._pending = None
+
+    def pin_host(self, on=True):
+        """LKFLOW_OPT_PIN_HOST: page-lock the caller's (re-used) host buffers in place for asynchronous DMA."""
+        self.set_option(LKFLOW_OPT_PIN_HOST, 1 if on else 0)
+
+    @staticmethod
+    def _host_u8(img):
+        a = np.asarray(img)
+        if a.dtype != np.uint8 or a.ndim != 2:
+            raise TypeError("expected a 2-D uint8 image")
+        if a.strides[1] != 1 or a.strides[0] < a.shape[1]:
+            a = np.ascontiguousarray(a)
+        return a
 
     def getLucasKanadeOpticalFlow(self, img1, img2, win=3):
         a, b = self._host_in(img1, False), self._host_in(img2, False)

@@ -28,23 +28,32 @@ def scatter_frames(frames_root, n_frames, height, width, src=0, device=None, dty
     rank, world = dist.get_rank(), dist.get_world_size()
     parts = partition(n_frames, world)
     first, n_local = parts[rank]
-    device = device if device is not None else (frames_root.device if frames_root is not None else "cpu")
+    # The device the messages travel on is fixed by the backend, on EVERY rank: RCCL ("nccl") moves device
+    # memory only, gloo moves host memory.  (Defaulting to the root tensor's device broke non-root ranks, which
+    # have no root tensor: they received into a CPU tensor under nccl.)
+    nccl = dist.get_backend() == "nccl"
+    wire = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    device = torch.device(device) if device is not None else wire
+    if nccl:
+        assert device.type == "cuda", "the nccl (RCCL) backend scatters into device memory"
     if rank == src:
         assert frames_root is not None and tuple(frames_root.shape) == (n_frames, height, width)
-        reqs = []
+        reqs, keep = [], []
         for r, (f0, n) in enumerate(parts):
             if r == src or n == 0:
                 continue
-            reqs.append(dist.isend(frames_root[f0:f0 + n].contiguous(), dst=r))
+            piece = frames_root[f0:f0 + n].to(wire).contiguous()   # host-side ingest rank under nccl: staged to the GPU
+            keep.append(piece)
+            reqs.append(dist.isend(piece, dst=r))
         local = frames_root[first:first + n_local].to(device).clone() if n_local else \
             torch.empty((0, height, width), dtype=dtype, device=device)
         for q in reqs:
             q.wait()
         return local
-    local = torch.empty((n_local, height, width), dtype=dtype, device=device)
+    local = torch.empty((n_local, height, width), dtype=dtype, device=wire)
     if n_local:
         dist.recv(local, src=src)
-    return local
+    return local.to(device)
 
 
 def gather_rows(local_rows, n_frames, dst=0):

@@ -292,6 +292,8 @@ static void lucas_kanade(const double *i1, const double *i2, int rows, int cols,
 /* ---- coarseToFineEstimation (ParallelVideoPyr.cpp:578-725) ---------------------------------- */
 
 int lkc_num_threads(void) { return omp_get_max_threads(); }
+/* mode 1 (all-cores row loops) uses omp_get_max_threads(): let the caller pin it to the cores it may really use */
+void lkc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 int lkc_coarse_to_fine(double *img1, double *img2, int rows, int cols, int levels, int win, int mode,
                        double *u, double *v)

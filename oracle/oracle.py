@@ -20,7 +20,10 @@ _fp = ctypes.POINTER(ctypes.c_float)
 def build(force=False):
     """Compile liblk_oracle.so / liblk_cpu_omp.so with gcc (a few seconds)."""
     targets = ["liblk_oracle.so", "liblk_cpu_omp.so"]
-    if force or not all(os.path.exists(os.path.join(_HERE, t)) for t in targets):
+    if force or not all(os.path.exists(os.path.join(_HERE, t)) and
+                        os.path.getmtime(os.path.join(_HERE, t)) >= max(os.path.getmtime(os.path.join(_HERE, s))
+                                                                         for s in ("lk_oracle.c", "lk_cpu_omp.c", "lk_oracle.h"))
+                        for t in targets):                  # (mtime test here: the GPU box may have no `make`-worthy clock skew)
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + targets)
 
 
@@ -224,6 +227,8 @@ def omp_lib():
         L.lkc_coarse_to_fine.restype = ctypes.c_int
         L.lkc_num_threads.argtypes = []
         L.lkc_num_threads.restype = ctypes.c_int
+        L.lkc_set_num_threads.argtypes = [ctypes.c_int]
+        L.lkc_set_num_threads.restype = None
         _OMP = L
     return _OMP
 

@@ -16,6 +16,17 @@ def test_algorithmic_bytes_match_survey_figures():
     # dominant kernel (LK at level 0): read 2 images + coarse u,v, write u,v = 36 B/px
     assert bench.lk0_bytes_per_pair(1920, 1080, 3) == 36 * 1920 * 1080
     assert set(bench.CONFIGS) >= {"1080p", "4k", "8k", "pacman", "webcam"}
+    # stream configs build P+1 pyramids for P pairs (not 2P): the pyramid term shrinks by (P+1)/(2P)
+    full, stream = bench.algorithmic_bytes_per_pair(240, 160, 3), bench.algorithmic_bytes_per_pair(240, 160, 3, stream_pairs=244)
+    pyr = 2 * 8 * ((240 * 160 + 120 * 80) + (120 * 80 + 60 * 40))
+    assert abs((full - stream) - pyr * (1 - 245 / 488)) <= 1
+
+
+def test_usable_cores_is_what_the_scheduler_allows():
+    import bench
+    cores, affinity, quota = bench.usable_cores()
+    assert 1 <= cores <= affinity == len(os.sched_getaffinity(0))
+    assert quota is None or quota > 0
 
 
 def test_committed_pmc_traffic_is_usable_by_bench():
@@ -23,7 +34,11 @@ def test_committed_pmc_traffic_is_usable_by_bench():
     workload and give a per-launch figure between the algorithmic bytes and twice that (aprons, halos)."""
     import bench
     cols, rows, levels, win, pairs = bench.CONFIGS["1080p"]
-    t = bench.measured_traffic(f"lk::lk_march3_kernel<{win}, ", cols, rows, pairs)
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+        import json
+        names = [k for k in json.load(fh) if k.startswith("lk::lk_") and k.endswith(", true>")]
+    assert names, "no level-0 LK kernel in profiles/pmc_traffic.json"
     alg = bench.lk0_bytes_per_pair(cols, rows, levels) * pairs
-    assert t is not None and alg <= t <= 2 * alg
-    assert bench.measured_traffic(f"lk::lk_march3_kernel<{win}, ", cols, rows, pairs + 1) is None   # other workloads: null
+    ts = [bench.measured_traffic(k, cols, rows, pairs) for k in names]
+    assert any(t is not None and alg <= t <= 2 * alg for t in ts)
+    assert all(bench.measured_traffic(k, cols, rows, pairs + 1) is None for k in names)   # other workloads: null

@@ -38,3 +38,12 @@ def test_cpp_dropin_reproduces_reference_goldens(tmp_path, goldens):
     assert np.abs(uv[0] - goldens["UPyrTest"]).max() <= 1e-6     # ParallelBasicPyr.cpp:787
     assert np.abs(uv[1] - goldens["VPyrTest"]).max() <= 1e-6
     assert np.abs(uv[2] - goldens["V2"]).max() <= 1e-6           # inputs were mutated in place
+
+
+def test_header_host_tail_and_mat_standin(tmp_path):
+    """include/lkflow.hpp's GPU-free pieces: gestureCentroid (ParallelVideoPyr.cpp:875-888) and lkflow::Mat."""
+    exe = str(tmp_path / "header_tail_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "header_tail_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,128 @@
+"""GPU suite (-m gpu), round 2 additions: full-size BASELINE configs 2 and 4 against
+the oracle, sharded == unsharded on the HIP path, two host threads with two contexts, the 8-bit and asynchronous
+host-buffer entry points.  Everything goes through the C ABI (lkflow_amd.Context)."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6        # ParallelBasicPyr.cpp:787
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    return torch
+
+
+def _omp_oracle(oracle, a, b, levels, win):
+    """oracle/lk_cpu_omp.c mode 1 (every stage row-parallel) on the cores this process may use: bit-identical to
+    oracle/lk_oracle.c (tests/test_oracle_golden.py::test_omp_baseline_is_bit_identical_to_oracle), minutes faster."""
+    import bench
+    oracle.omp_lib().lkc_set_num_threads(bench.usable_cores()[0])
+    return oracle.omp_coarse_to_fine(a, b, levels, win, 1)
+
+
+@pytest.mark.parametrize("rows,cols,levels,win,seed", [(2160, 3840, 5, 21, 7), (4320, 7680, 5, 31, 9)],
+                         ids=["config2_4k_L5_w21", "config4_8k_L5_w31"])
+def test_full_size_config_vs_oracle(gpu_ctx, oracle, rows, cols, levels, win, seed):
+    """BASELINE configs 2 and 4 at FULL size, one pair, against the CPU oracle: pins pyrDown, warp and LK at
+    these sizes (the march == per-pixel tests share pyrDown and warp between their two legs)."""
+    import synth
+    a, b = synth.frame_pair(rows, cols, seed=seed)
+    u, v = gpu_ctx.computeFlow(a, b, levels, win)
+    uo, vo = _omp_oracle(oracle, a, b, levels, win)
+    scale = max(1.0, np.abs(uo).max(), np.abs(vo).max())
+    du, dv = np.abs(u - uo).max(), np.abs(v - vo).max()
+    print(f"{cols}x{rows} L{levels} w{win}: max|du|={du:.3e} max|dv|={dv:.3e} (flow range {scale:.1f} px)")
+    assert du <= TOL * scale and dv <= TOL * scale
+
+
+def test_sharded_stream_equals_unsharded_on_gpu(gpu_ctx, lkflow, torch):
+    """SURVEY.md 8(e) "Check" on the HIP path, in one process: the same 9-frame uint8 stream as ONE shard and as
+    2 and 3 shards (shard_pairs + stream_flow per shard, what every rank of `bench.py --gpus N` runs) gives
+    bit-identical U, V and centroid rows for every pair."""
+    import sharding
+    import synth
+    F, H, W, L, win = 9, 160, 240, 3, 15
+    frames = torch.from_numpy(np.clip(np.rint(synth.video(F, H, W, seed=21) * 255.0), 0, 255).astype(np.uint8)).cuda()
+    U1, V1, R1 = sharding.stream_flow(frames, gpu_ctx, L, win, thresh=0.5)
+    assert U1.shape == (F - 1, H, W) and R1.shape == (F - 1, 3)
+    for world in (2, 3, 8):
+        seen = 0
+        for rank in range(world):
+            first, n = lkflow.shard_pairs(F, world, rank)
+            if n == 0:
+                continue
+            U, V, R = sharding.stream_flow(frames[first:first + n].clone(), gpu_ctx, L, win, thresh=0.5)
+            assert torch.equal(U, U1[first:first + n - 1]) and torch.equal(V, V1[first:first + n - 1])
+            assert torch.equal(R, R1[first:first + n - 1])
+            seen += n - 1
+        assert seen == F - 1
+
+
+def test_two_host_threads_two_contexts(lkflow, torch):
+    """The header promises "thread-safe per context": two host threads, one context each, concurrently; every
+    result equals the single-threaded one bit for bit (the occupancy caches live in the context now)."""
+    import synth
+    shapes = [(272, 480, 3, 15), (288, 512, 4, 9)]
+    inputs = [synth.frame_pairs_torch(3, h, w, "cuda", seed=40 + k) for k, (h, w, _, _) in enumerate(shapes)]
+    ref = []
+    with lkflow.Context(0) as c:
+        for (h, w, lv, win), (p, n) in zip(shapes, inputs):
+            ref.append(c.compute_batch(p, n, lv, win))
+        torch.cuda.synchronize()
+    out, err = [None, None], []
+
+    def work(k):
+        try:
+            with lkflow.Context(0) as c:
+                s = torch.cuda.Stream()
+                for _ in range(6):                     # fresh context each thread: first-use occupancy queries race here
+                    out[k] = c.compute_batch(inputs[k][0], inputs[k][1], shapes[k][2], shapes[k][3], stream=s)
+                s.synchronize()
+        except Exception as e:                         # noqa: BLE001
+            err.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for k in range(2):
+        assert torch.equal(out[k][0], ref[k][0]) and torch.equal(out[k][1], ref[k][1])
+
+
+def test_u8_and_async_host_entry_points(gpu_ctx, lkflow, oracle, table_u8, goldens):
+    """lkflow_compute_u8 == lkflow_compute_f64 on convertTo(1/255) of the same frames, bit for bit (and so the
+    reference's UPyrTest/VPyrTest at 1e-6); lkflow_enqueue_pair_* + lkflow_wait give the same arrays, with and
+    without LKFLOW_OPT_PIN_HOST."""
+    a8, b8 = table_u8
+    a, b = oracle.u8_to_f64(a8), oracle.u8_to_f64(b8)
+    u, v = gpu_ctx.computeFlow(a, b, 7, 3)
+    u8, v8 = gpu_ctx.computeFlow_u8(a8, b8, 7, 3)
+    assert np.array_equal(u, u8) and np.array_equal(v, v8)
+    assert np.abs(u8 - goldens["UPyrTest"]).max() <= TOL and np.abs(v8 - goldens["VPyrTest"]).max() <= TOL
+    for pin in (False, True):
+        with lkflow.Context(0) as c:
+            c.pin_host(pin)
+            for _ in range(2):                         # second round re-uses the registered buffers
+                ua, va = c.enqueue_pair(a, b, 7, 3)
+                c.wait()
+                assert np.array_equal(ua, u) and np.array_equal(va, v)
+                ub, vb = c.enqueue_pair(a8, b8, 7, 3)
+                uc, vc = c.enqueue_pair(a, b, 7, 3)    # a second enqueue first waits for the first
+                c.wait()
+                assert np.array_equal(ub, u) and np.array_equal(vb, v) and np.array_equal(uc, u) and np.array_equal(vc, v)
+            c.pin_host(False)
+    # strided 8-bit input (a ROI of a wider frame) and argument errors
+    wide = np.zeros((448, 700), dtype=np.uint8)
+    wide[:, :640] = a8
+    wide2 = np.zeros((448, 700), dtype=np.uint8)
+    wide2[:, :640] = b8
+    us, vs = gpu_ctx.computeFlow_u8(wide[:, :640], wide2[:, :640], 7, 3)
+    assert np.array_equal(us, u) and np.array_equal(vs, v)
+    with pytest.raises(lkflow.LKFlowError):
+        gpu_ctx.computeFlow_u8(a8, b8, 8, 3)           # more levels than getMaxLayer
