@@ -382,7 +382,8 @@ def spawn_ranks(n):
     rc = procs[0].returncode
     for p in procs[1:]:
         rc = rc or p.wait()
-    sys.stdout.write(out.decode())
+    for line in out.decode().splitlines():                  # ONE JSON line on stdout; anything else a library printed
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")   # there (gloo's connection notes) -> stderr
     sys.stdout.flush()
     raise SystemExit(rc)
 
@@ -517,7 +518,7 @@ def main():
         dt = t.item()
 
     stream_extra = None
-    if dist is not None and not args.no_extras and not rehearse:
+    if dist is not None and not args.no_extras:
         del prev, nxt, U, V
         torch.cuda.empty_cache()
         stream_extra = stream_sharding_extra(lkf, torch, dist, synth, ctx, args.config, dev, rank, world)

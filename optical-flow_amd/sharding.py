@@ -21,6 +21,14 @@ def partition(n_frames, world_size):
     return [shard_pairs(n_frames, world_size, r) for r in range(world_size)]
 
 
+def _wire():
+    """The device messages travel on, fixed by the backend on EVERY rank: RCCL ("nccl") moves device memory only,
+    gloo (the CPU test-suite, the one-GPU rehearsal) moves host memory."""
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def scatter_frames(frames_root, n_frames, height, width, src=0, device=None, dtype=torch.uint8):
     """Root `src` holds frames_root [F,H,W] (dtype); every rank returns its block
     [n_local, H, W] on `device`.  Point-to-point sends of exactly the needed frames (xGMI is
@@ -28,13 +36,11 @@ def scatter_frames(frames_root, n_frames, height, width, src=0, device=None, dty
     rank, world = dist.get_rank(), dist.get_world_size()
     parts = partition(n_frames, world)
     first, n_local = parts[rank]
-    # The device the messages travel on is fixed by the backend, on EVERY rank: RCCL ("nccl") moves device
-    # memory only, gloo moves host memory.  (Defaulting to the root tensor's device broke non-root ranks, which
-    # have no root tensor: they received into a CPU tensor under nccl.)
-    nccl = dist.get_backend() == "nccl"
-    wire = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    # (Defaulting to the root tensor's device broke non-root ranks, which have no root tensor: they received into a
+    # CPU tensor under nccl.)
+    wire = _wire()
     device = torch.device(device) if device is not None else wire
-    if nccl:
+    if wire.type == "cuda":
         assert device.type == "cuda", "the nccl (RCCL) backend scatters into device memory"
     if rank == src:
         assert frames_root is not None and tuple(frames_root.shape) == (n_frames, height, width)
@@ -62,6 +68,7 @@ def gather_rows(local_rows, n_frames, dst=0):
     rank, world = dist.get_rank(), dist.get_world_size()
     parts = partition(n_frames, world)
     k = local_rows.shape[1]
+    wire = _wire()
     if rank == dst:
         out = torch.empty((max(n_frames - 1, 0), k), dtype=local_rows.dtype, device=local_rows.device)
         for r, (f0, n) in enumerate(parts):
@@ -71,12 +78,12 @@ def gather_rows(local_rows, n_frames, dst=0):
             if r == dst:
                 out[f0:f0 + cnt] = local_rows
             else:
-                buf = torch.empty((cnt, k), dtype=local_rows.dtype, device=local_rows.device)
+                buf = torch.empty((cnt, k), dtype=local_rows.dtype, device=wire)
                 dist.recv(buf, src=r)
-                out[f0:f0 + cnt] = buf
+                out[f0:f0 + cnt] = buf.to(out.device)
         return out
     if local_rows.shape[0]:
-        dist.send(local_rows.contiguous(), dst=dst)
+        dist.send(local_rows.to(wire).contiguous(), dst=dst)
     return None
 
 
