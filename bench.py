@@ -269,29 +269,32 @@ def copy_ceiling(torch, device, nbytes=2 << 30, reps=10):
 def host_call_rate(ctx, cols, rows, levels, win, reps=5):
     """Extra: the host-buffer drop-in calls (the cv::Mat entry points): host arrays in, host arrays out, synchronous --
     i.e. the PCIe-inclusive rate of one pair.  Never `value`.  f64 = lkflow_compute_f64 (CV_64F frames, 8 B/px up),
-    u8 = lkflow_compute_u8 (8-bit frames, convertTo(1/255) on the device, 1 B/px up)."""
+    u8 = lkflow_compute_u8 (8-bit frames, convertTo(1/255) on the device, 1 B/px up); each from pageable memory and
+    with LKFLOW_OPT_PIN_HOST (the loop's re-used buffers page-locked in place once: true DMA)."""
     import numpy as np
     import synth
     a, b = synth.frame_pair(rows, cols, seed=99)
-    ctx.computeFlow(a, b, levels, win)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        ctx.computeFlow(a, b, levels, win)
-    dt = (time.perf_counter() - t0) / reps
-    out = {"ms_per_pair": round(dt * 1e3, 3), "Mpixels_per_s": round(rows * cols / dt / 1e6, 1),
-           "bytes_over_pcie_per_pair": 4 * rows * cols * 8,
-           "note": "rank 0 only, extra: 2 planes H2D + 2 planes D2H through the context's pinned bounce buffers "
-                   "around the same kernels"}
-    if hasattr(ctx, "computeFlow_u8"):
-        a8 = np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)
-        b8 = np.clip(np.rint(b * 255.0), 0, 255).astype(np.uint8)
-        ctx.computeFlow_u8(a8, b8, levels, win)
+    a8 = np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)
+    b8 = np.clip(np.rint(b * 255.0), 0, 255).astype(np.uint8)
+    u, v = np.empty((rows, cols)), np.empty((rows, cols))
+
+    def timed(x, y):
+        ctx.enqueue_pair(x, y, levels, win, out=(u, v)); ctx.wait()
         t0 = time.perf_counter()
         for _ in range(reps):
-            ctx.computeFlow_u8(a8, b8, levels, win)
-        dt8 = (time.perf_counter() - t0) / reps
-        out["u8_in"] = {"ms_per_pair": round(dt8 * 1e3, 3), "Mpixels_per_s": round(rows * cols / dt8 / 1e6, 1),
-                        "bytes_over_pcie_per_pair": 2 * rows * cols + 2 * rows * cols * 8}
+            ctx.enqueue_pair(x, y, levels, win, out=(u, v)); ctx.wait()
+        dt = (time.perf_counter() - t0) / reps
+        return {"ms_per_pair": round(dt * 1e3, 3), "Mpixels_per_s": round(rows * cols / dt / 1e6, 1)}
+    out = dict(timed(a, b), bytes_over_pcie_per_pair=4 * rows * cols * 8,
+               note="rank 0 only, extra: 2 planes H2D + 2 planes D2H from pageable memory around the same kernels "
+                    "(lkflow_enqueue_pair_f64 + lkflow_wait = lkflow_compute_f64)")
+    out["u8_in"] = dict(timed(a8, b8), bytes_over_pcie_per_pair=2 * rows * cols + 2 * rows * cols * 8)
+    ctx.pin_host(True)
+    try:
+        out["pinned"] = {"f64_in": timed(a, b), "u8_in": timed(a8, b8),
+                         "note": "LKFLOW_OPT_PIN_HOST: the same (re-used) host arrays page-locked in place"}
+    finally:
+        ctx.pin_host(False)
     return out
 
 

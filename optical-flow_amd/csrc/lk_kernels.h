@@ -245,6 +245,7 @@ struct LKArgs {
     CPlanes cu, cv;   // coarse total flow (H/2 x W/2), only if HAS_UP
     int H, W;
     int th;           // output rows per block
+    int gx, gy;       // lk_split: column blocks / row strips per pair (1-D grid, XCD-aware tile order)
     unsigned long long *dbg;   // diagnostic builds only (LK3_STAMPS): per-wave segment cycle totals
 };
 

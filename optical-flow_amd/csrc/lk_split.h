@@ -40,7 +40,13 @@
 #include "lk_w3x2.h"     // buf_ld2 (16-byte buffer loads), lk_march3.h
 
 #ifndef LK_SPLIT_PF
-#define LK_SPLIT_PF 4
+#define LK_SPLIT_PF 2    /* image rows an F lane keeps in flight (2, 4, 8: no measurable difference) */
+#endif
+#ifndef LK_SPLIT_PRIO_F
+#define LK_SPLIT_PRIO_F 3
+#endif
+#ifndef LK_SPLIT_TD
+#define LK_SPLIT_TD 2    /* even: row pairs of coarse taps a B lane keeps in flight (4 spills at 15x15 and is slower) */
 #endif
 
 #ifdef LK_SPLIT_STAMPS   /* diagnostic build: per-wave segment cycle totals -> a.dbg (tools/split_stamps_summary.py) */
@@ -80,10 +86,10 @@ struct SplitCfg {
 #else
     static constexpr int WPE = (K == 2 && WIN <= 21) ? 4 : 1;   // waves per SIMD to compile for (8-wave blocks: 4 -> two blocks per CU)
 #endif
-    static constexpr int UN = 2;                     // unrolled F group in steps (LDS buffer parity; queue slots of 4 rows)
+    static constexpr int UN = PF >= 4 ? PF / 2 : 2;  // unrolled F group in steps: even (LDS buffer parity) and PF rows (queue slots)
     static_assert(K == 2, "one F wave feeds 126 columns: S lanes own 2 columns (K = 4 ran one 11-wave block per CU: slower)");
     static_assert(PSTR >= NJP, "product half-planes must not overlap");
-    static_assert(PF == 2 || PF == 4, "static queue slots: two rows per step, two steps per group");
+    static_assert(PF == 2 || (PF % 4 == 0 && PF <= 16), "static queue slots: two rows per step, an even number of steps per group");
 };
 
 // tree sum of v[LO..HI] (compile-time bounds)
@@ -102,24 +108,35 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 {
     using C = SplitCfg<WIN, K>;
     constexpr int R = C::R, TXC = C::TXC, XO = C::XO, KH = C::KH, PADJ = C::PADJ, PF = C::PF, UN = C::UN, HL = C::HL;
-    __shared__ __attribute__((aligned(16))) double s_prod[2][2][5][C::PROD_D];   // [step parity][row of the step][field]
+    __shared__ __attribute__((aligned(16))) double s_prod[2][2][5][C::PROD_D];   // [step parity][row of the step][field]: (a, b) products of every column pair
+    __shared__ double s_q[2][2][5][C::NJP];                                       // the pair sums a + b (index = chunk)
     __shared__ __attribute__((aligned(16))) double s_sums[2][2][5][C::SUMS_D];
 
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 #ifdef LK_SPLIT_STAMPS
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
 #endif
-    const int pair = blockIdx.z;
+    // 1-D grid, XCD-aware tile order (lk_kernels.h): workgroups are dealt round-robin over the 8 XCDs (private L2s), so
+    // with the natural order the column blocks of one strip -- which share 2 HL halo columns -- and vertically adjacent
+    // strips -- which share 2R apron rows -- land on different L2s and every shared line is fetched from HBM once per XCD
+#ifdef LK_SPLIT_NO_XCD
+    unsigned tile = blockIdx.x;
+#else
+    unsigned tile = xcd_tile_id(blockIdx.x, gridDim.x);
+#endif
+    const int bx = tile % a.gx; tile /= a.gx;
+    const int by = tile % a.gy;
+    const int pair = tile / a.gy;
     const int H = a.H, W = a.W;
-    const int y0 = blockIdx.y * a.th;                // even (host)
+    const int y0 = by * a.th;                        // even (host)
     const int y1 = min(y0 + a.th, H);
     const int nrows = y1 - y0;                       // even (H is even or the strip height is: host)
     const int nm = nrows + 2 * R;                    // marched product rows: image rows y0-R .. y1-1+R
     const int yy0 = y0 - R;
-    const int x0 = (int)blockIdx.x * XO - HL;        // image column of block column 0 (even)
+    const int x0 = bx * XO - HL;                     // image column of block column 0 (even)
     const int nsw = nm / 2;                          // steps in which F (and, one step later, S) has rows
     const int ns = nsw + 2;                          // pipeline steps: B trails F by two
-    const int NS = ns + (ns & 1);                    // barriers per wave: padded to whole F groups (idle tail step)
+    const int NS = (ns + UN - 1) / UN * UN;          // barriers per wave: padded to whole F groups (idle tail steps)
 
     // zero the pad lanes of the product planes once (only non-output columns ever read them)
     constexpr int PZ = PADJ + 1;                      // right side: the pads and the chunk of columns TXC, TXC + 1
@@ -129,6 +146,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         const int chunk = h * C::PSTR + (side ? PADJ + 63 + pj : min(pj, PADJ - 1));
         s_prod[b >> 1][b & 1][f][2 * chunk] = 0.0;
         s_prod[b >> 1][b & 1][f][2 * chunk + 1] = 0.0;
+        s_q[b >> 1][b & 1][f][chunk] = 0.0;
     }
     __syncthreads();
 
@@ -136,6 +154,9 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         // =========================================================================================
         // F waves: two adjacent columns per lane -> products
         // =========================================================================================
+        // the one wave that feeds the block's pipeline from memory issues ahead of the seven that consume (A/B: level-0
+        // launch 0.80 -> 0.77 ms; raising B instead, or both, gains nothing)
+        __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_F);
         const int m = (int)threadIdx.x - 64 * (C::NB + 5);   // lane: block columns 2(m-1), 2(m-1)+1; lane 0 = the pair left of the block
         const int xa = x0 + 2 * (m - 1);             // even; W even: the pair is all in or all out
         const int pitchb = (int)a.i1.pitch * 8;
@@ -182,33 +203,55 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 
         // one marched row i (queue slot QS = i % PF, static): prefetch row i + PF into the slot the last rotate
         // freed, products of row i -> LDS plane (SP, E), rotate row i + 1 in
-        auto frow = [&](auto spc, auto ec, int i) __attribute__((always_inline)) {
-            constexpr int SP = decltype(spc)::value, E = decltype(ec)::value;
-            constexpr int QS = (2 * SP + E) % PF;
+        auto frow = [&](auto uc, auto ec, int i) __attribute__((always_inline)) {
+            constexpr int U = decltype(uc)::value, E = decltype(ec)::value;
+            constexpr int SP = U & 1;                        // LDS plane of the step
+            constexpr int QS = (2 * U + E) % PF;
             {
                 const int rn = img_row_off(yy0 + i + PF);
+#ifdef LK_SPLIT_ABL_NOLOAD
+                qa[QS][0] = qb[QS][0] = (double)rn; qa[QS][1] = qb[QS][1] = 1.0;
+#else
                 buf_ld2(rI1, vxc, rn, qa[QS][0], qb[QS][0]);
                 buf_ld2(rI2, vxc, rn, qa[QS][1], qb[QS][1]);
+#endif
             }
             const int yy = yy0 + i;
             const bool row_in = yy >= 0 && yy < H;
+#ifdef LK_SPLIT_ABL_F   /* timing-only ablation build: no derivative arithmetic */
+            double fxa = ca[0], fya = ca[1], fxb = cb[0], fyb = cb[1];
+            const double fta = pl[0] + cl[0], ftb = pl[1] + cl[1] + pa[0] + pb[1];
+#else
             double fxa = f2d_x(pl[0], pa[0], cl[0], ca[0]) + f2d_x(pl[1], pa[1], cl[1], ca[1]);
             double fya = f2d_y(pl[0], pa[0], cl[0], ca[0]) + f2d_y(pl[1], pa[1], cl[1], ca[1]);
             const double fta = f2d_neg(pl[0], pa[0], cl[0], ca[0]) + f2d_pos(pl[1], pa[1], cl[1], ca[1]);
             double fxb = f2d_x(pa[0], pb[0], ca[0], cb[0]) + f2d_x(pa[1], pb[1], ca[1], cb[1]);
             double fyb = f2d_y(pa[0], pb[0], ca[0], cb[0]) + f2d_y(pa[1], pb[1], ca[1], cb[1]);
             const double ftb = f2d_neg(pa[0], pb[0], ca[0], cb[0]) + f2d_pos(pa[1], pb[1], ca[1], cb[1]);
+#endif
             if (!(row_in && all_col_in)) {                  // rows / columns outside the image contribute 0 (wave-uniform test)
                 const bool keep = row_in && col_in;
                 fxa = keep ? fxa : 0.0; fya = keep ? fya : 0.0;
                 fxb = keep ? fxb : 0.0; fyb = keep ? fyb : 0.0;
             }
             lk_d2 o;
-            o.x = fxa * fxa; o.y = fxb * fxb; *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][0][2 * p_chunk]) = o;
-            o.x = fya * fya; o.y = fyb * fyb; *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][1][2 * p_chunk]) = o;
-            o.x = fxa * fya; o.y = fxb * fyb; *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][2][2 * p_chunk]) = o;
-            o.x = fxa * fta; o.y = fxb * ftb; *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][3][2 * p_chunk]) = o;
-            o.x = fya * fta; o.y = fyb * ftb; *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][4][2 * p_chunk]) = o;
+            // per field: the two products as one 16-byte store, their sum (what S adds up for the shared part of the
+            // two windows of a column pair) as one 8-byte store
+            auto put = [&](auto fc, double xa_, double xb_) __attribute__((always_inline)) {
+                constexpr int FI = decltype(fc)::value;
+                o.x = xa_; o.y = xb_;
+#ifdef LK_SPLIT_ABL_NOFLDS
+                if (xa_ == 12345.678) s_q[SP][E][FI][p_chunk] = xa_ + xb_;
+#else
+                *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][FI][2 * p_chunk]) = o;
+                s_q[SP][E][FI][p_chunk] = xa_ + xb_;
+#endif
+            };
+            put(std::integral_constant<int, 0>{}, fxa * fxa, fxb * fxb);
+            put(std::integral_constant<int, 1>{}, fya * fya, fyb * fyb);
+            put(std::integral_constant<int, 2>{}, fxa * fya, fxb * fyb);
+            put(std::integral_constant<int, 3>{}, fxa * fta, fxb * ftb);
+            put(std::integral_constant<int, 4>{}, fya * fta, fyb * ftb);
             // rotate: the only wait for the prefetch
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -229,14 +272,18 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             SP_STAMP(t2);
             SP_ACC(0, t0, t1); SP_ACC(3, t1, t2);
         };
-        for (int st = 0; st < NS; st += 2) {                 // NS is even: no guards inside a group
-            fstep(std::integral_constant<int, 0>{}, st);
-            fstep(std::integral_constant<int, 1>{}, st + 1);
+        for (int st = 0; st < NS; st += UN) {                // NS is a multiple of UN: no guards inside a group
+            [&]<int... Us>(std::integer_sequence<int, Us...>) __attribute__((always_inline)) {
+                (fstep(std::integral_constant<int, Us>{}, st + Us), ...);
+            }(std::make_integer_sequence<int, UN>{});
         }
     } else if (wv < C::NB) {
         // =========================================================================================
         // B waves: one column per lane: window sums -> flow
         // =========================================================================================
+#ifdef LK_SPLIT_PRIO_B
+        __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_B);
+#endif
         const int t = threadIdx.x;                   // block column 0 .. TXC-1
         const int x = x0 + t;
         const int xc = min(max(x, 0), W - 1);
@@ -249,9 +296,15 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 
         [[maybe_unused]] UpSel1 us{};
         [[maybe_unused]] double hu[3] = {0, 0, 0}, hv[3] = {0, 0, 0};   // carried coarse rows (rotated every even row)
-        [[maybe_unused]] double tp[2][6];                               // taps of the next coarse rows (u: 0..2, v: 3..5), two in flight
+        // taps of the next coarse rows (u: 0..2, v: 3..5): a queue TD row pairs deep.  A step is shorter than an L2 / HBM
+        // round trip, and vmcnt is in-order, so a tap that was fetched one step ahead also waited for every older
+        // store of this wave (timing-only ablations: removing the stores alone saved 0.12 of 0.69 ms)
+        constexpr int TD = LK_SPLIT_TD;
+        [[maybe_unused]] double tp[TD][6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) tp[0][k] = tp[1][k] = 0.0;
+        for (int q = 0; q < TD; ++q)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tp[q][k] = 0.0;
         [[maybe_unused]] const int Hc = H >> 1;
         [[maybe_unused]] const int cpub = (int)a.cu.pitch * 8, cpvb = (int)a.cv.pitch * 8;
         [[maybe_unused]] const int crow_lo = max((y0 >> 1) - 1, 0);
@@ -279,10 +332,13 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                 hu[(s + 1) % 3] = pyrup_h1v(buf_ld(rCU, us.jm, sr * cpub), buf_ld(rCU, us.jc, sr * cpub), buf_ld(rCU, us.jp, sr * cpub), us);
                 hv[(s + 1) % 3] = pyrup_h1v(buf_ld(rCV, us.jm, sr * cpvb), buf_ld(rCV, us.jc, sr * cpvb), buf_ld(rCV, us.jp, sr * cpvb), us);
             }
-            int su, sv;
-            tap_off(y0 - 1, su, sv);                            // taps the first odd row (y0 + 1) consumes -> buffer 0
-            tp[0][0] = buf_ld(rCU, us.jm, su); tp[0][1] = buf_ld(rCU, us.jc, su); tp[0][2] = buf_ld(rCU, us.jp, su);
-            tp[0][3] = buf_ld(rCV, us.jm, sv); tp[0][4] = buf_ld(rCV, us.jc, sv); tp[0][5] = buf_ld(rCV, us.jp, sv);
+#pragma unroll
+            for (int q = 0; q < TD - 1; ++q) {                  // taps that the odd rows of pairs 0 .. TD-2 consume -> slots 0 .. TD-2
+                int su, sv;
+                tap_off(y0 + 2 * q - 1, su, sv);
+                tp[q][0] = buf_ld(rCU, us.jm, su); tp[q][1] = buf_ld(rCU, us.jc, su); tp[q][2] = buf_ld(rCU, us.jp, su);
+                tp[q][3] = buf_ld(rCV, us.jm, sv); tp[q][4] = buf_ld(rCV, us.jc, sv); tp[q][5] = buf_ld(rCV, us.jp, sv);
+            }
         }
         const int vxo = x * 8;
         int sou = 0, sov = 0;                                   // byte offsets of output row r in the u / v strips
@@ -293,6 +349,9 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         // unconditionally (see the file header); the two solves are independent and interleave.
         const int vo_lane = is_out ? vxo : (int)0x80000000;   // out of range: the store is dropped
         auto solve5 = [&](const double (&S)[5], bool inner, double &u, double &v) __attribute__((always_inline)) {
+#ifdef LK_SPLIT_ABL_B   /* timing-only ablation build: no solve */
+            u = inner ? S[0] + S[2] + S[4] : 0.0; v = inner ? S[1] + S[3] : 0.0; return;
+#endif
             const double det = S[0] * S[1] - S[2] * S[2];
             const double un = S[2] * S[4] - S[1] * S[3];
             const double vn = S[3] * S[2] - S[0] * S[4];
@@ -321,14 +380,15 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             }
         };
         auto bpair = [&](auto pc2, auto fastc, int p) __attribute__((always_inline)) {
-            constexpr int P2 = decltype(pc2)::value;
+            constexpr int P2 = decltype(pc2)::value;        // p mod TD
             constexpr int SPB = (P2 + R) & 1;
+            constexpr int TN = (P2 + TD - 1) % TD;          // the slot this pair's own taps just left
             const int y = y0 + 2 * p;
-            if constexpr (HAS_UP) {                         // taps consumed by the NEXT pair's odd row (y + 3)
+            if constexpr (HAS_UP) {                         // taps consumed by the odd row of pair p + TD - 1
                 int su, sv;
-                tap_off(y + 1, su, sv);
-                tp[P2 ^ 1][0] = buf_ld(rCU, us.jm, su); tp[P2 ^ 1][1] = buf_ld(rCU, us.jc, su); tp[P2 ^ 1][2] = buf_ld(rCU, us.jp, su);
-                tp[P2 ^ 1][3] = buf_ld(rCV, us.jm, sv); tp[P2 ^ 1][4] = buf_ld(rCV, us.jc, sv); tp[P2 ^ 1][5] = buf_ld(rCV, us.jp, sv);
+                tap_off(y + 2 * (TD - 1) - 1, su, sv);
+                tp[TN][0] = buf_ld(rCU, us.jm, su); tp[TN][1] = buf_ld(rCU, us.jc, su); tp[TN][2] = buf_ld(rCU, us.jp, su);
+                tp[TN][3] = buf_ld(rCV, us.jm, sv); tp[TN][4] = buf_ld(rCV, us.jc, sv); tp[TN][5] = buf_ld(rCV, us.jp, sv);
             }
             double S0[5], S1[5];
 #pragma unroll
@@ -349,10 +409,14 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                 hu[0] = pyrup_h1v(tp[P2][0], tp[P2][1], tp[P2][2], us);   // next coarse row, used from the next pair on
                 hv[0] = pyrup_h1v(tp[P2][3], tp[P2][4], tp[P2][5], us);
             }
+#ifdef LK_SPLIT_ABL_NOSTORE
+            if (ue + ve + uo + vo == 12345.678) buf_st(rU, vo_lane, sou, ue);
+#else
             buf_st(rU, vo_lane, sou, ue);
             buf_st(rV, vo_lane, sov, ve);
             buf_st(rU, vo_lane, sou + upb, uo);
             buf_st(rV, vo_lane, sov + vpb, vo);
+#endif
             sou += 2 * upb; sov += 2 * vpb;
         };
         auto bstep = [&](auto pc2, int p) __attribute__((always_inline)) {
@@ -367,20 +431,32 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         for (int k = 0; k < R + 2; ++k) __syncthreads();       // pipeline fill: no window sums yet
         const int npairs = nrows / 2;
         int p = 0;
-        for (; p + 2 <= npairs; p += 2) {                       // whole groups
-            bstep(std::integral_constant<int, 0>{}, p);
-            bstep(std::integral_constant<int, 1>{}, p + 1);
+        for (; p + TD <= npairs; p += TD) {                     // whole groups
+            [&]<int... Ps>(std::integer_sequence<int, Ps...>) __attribute__((always_inline)) {
+                (bstep(std::integral_constant<int, Ps>{}, p + Ps), ...);
+            }(std::make_integer_sequence<int, TD>{});
         }
-        if (p < npairs) bstep(std::integral_constant<int, 0>{}, p);
-        for (int k = ns; k < NS; ++k) __syncthreads();          // idle tail step
+        [&]<int... Ps>(std::integer_sequence<int, Ps...>) __attribute__((always_inline)) {   // last, partial group
+            ((p + Ps < npairs ? (bstep(std::integral_constant<int, Ps>{}, p + Ps), 0) : 0), ...);
+        }(std::make_integer_sequence<int, TD - 1>{});
+        for (int k = ns; k < NS; ++k) __syncthreads();          // idle tail steps
     } else {
         // =========================================================================================
         // S waves: one field each, K adjacent columns per lane
         // =========================================================================================
         const int f = wv - C::NB;
         const int j = threadIdx.x & 63;
-        constexpr int NV = K * (2 * PADJ + 1);               // raw values a lane can see: offsets -K*PADJ .. K*PADJ+K-1
-        constexpr int O0 = K * PADJ;                         // index of column offset 0
+        // Horizontal windows of the lane's column pair (2j, 2j+1) from the pair sums q and two single products:
+        //   R odd : shared = q[j-(R-1)/2 .. j+(R-1)/2];          out0 = b[j-(R+1)/2] + shared;  out1 = shared + a[j+(R+1)/2]
+        //   R even: shared = q[j-(R/2-1) .. j+(R/2-1)];  out0 = q[j-R/2] + shared + a[j+R/2];  out1 = b[j-R/2] + shared + q[j+R/2]
+        // (R or R+1 eight-byte LDS reads + 2 and R+1 or R+2 additions per row, against 2R+2 values and 2R+1 additions
+        // from the raw products; additions only).  NQ values of q starting at lane offset QLO, singles at offsets -HS, +HS.
+        constexpr bool RODD = (R & 1) != 0;
+        constexpr int HS = RODD ? (R + 1) / 2 : R / 2;       // lane offset of the two single products
+        constexpr int QH = RODD ? (R - 1) / 2 : R / 2;       // q values are read for lane offsets -QH .. +QH
+        constexpr int NQ = 2 * QH + 1;
+        static_assert(K == 2 && HS <= PADJ, "pad lanes cover the taps");
+        struct SRow { double q[NQ], sb, sa; };
         double ring[WIN][K], pre[K];
 #pragma unroll
         for (int q = 0; q < WIN; ++q)
@@ -389,44 +465,38 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 #pragma unroll
         for (int c = 0; c < K; ++c) pre[c] = 0.0;
 
-        auto srow = [&](auto kc, auto ec, int i) __attribute__((always_inline)) {
-            constexpr int KC = decltype(kc)::value, E = decltype(ec)::value;
-            const double *pp = &s_prod[(i >> 1) & 1][E][f][0];
-            double v[NV];
+        auto sload = [&](auto ec, int i, SRow &r) __attribute__((always_inline)) {
+            constexpr int E = decltype(ec)::value;
+            const double *qq = &s_q[(i >> 1) & 1][E][f][PADJ + j];
+            const double *pp = &s_prod[(i >> 1) & 1][E][f][2 * (PADJ + j)];
+#ifdef LK_SPLIT_ABL_NOSLDS
 #pragma unroll
-            for (int d = -PADJ; d <= PADJ; ++d)
+            for (int d = 0; d < NQ; ++d) r.q[d] = (double)(i + d);
+            r.sb = 1.0; r.sa = (double)(qq - pp);
+#else
 #pragma unroll
-                for (int h = 0; h < KH; ++h) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int o0 = K * d + 2 * h;            // column offsets o0, o0 + 1
-                    if (o0 + 1 >= -R && o0 <= K - 1 + R) {
-                        const lk_d2 c2 = *reinterpret_cast<const lk_d2 *>(pp + 2 * (h * C::PSTR + PADJ + j + d));
-                        v[O0 + o0] = c2.x; v[O0 + o0 + 1] = c2.y;
-                    } else {
-                        v[O0 + o0] = 0.0; v[O0 + o0 + 1] = 0.0;
-                    }
-                }
-            // horizontal windows of the K columns: shared core [K-1-R, R] + left / right extensions
-            const double core = split_tree<O0 + K - 1 - R, O0 + R>(v);
+            for (int d = 0; d < NQ; ++d) r.q[d] = qq[d - QH];
+            r.sb = pp[-2 * HS + 1];                          // b of pair j - HS
+            r.sa = pp[2 * HS];                               // a of pair j + HS
+#endif
+        };
+        // horizontal windows + vertical van Herk step at static chunk position KC -> the K window sums of row i
+        auto ssum = [&](auto kc, const SRow &r, double (&S)[K]) __attribute__((always_inline)) {
+            constexpr int KC = decltype(kc)::value;
             double hs[K];
-            {
-                double L[K], Rr[K];                          // L[m] = sum of the m columns left of the core, Rr[m] likewise right
-                L[0] = 0.0; Rr[0] = 0.0;
-#pragma unroll
-                for (int m = 1; m < K; ++m) {
-                    L[m] = (m == 1) ? v[O0 + K - 1 - R - 1] : L[m - 1] + v[O0 + K - 1 - R - m];
-                    Rr[m] = (m == 1) ? v[O0 + R + 1] : Rr[m - 1] + v[O0 + R + m];
-                }
-#pragma unroll
-                for (int c = 0; c < K; ++c) {
-                    double s = core;
-                    if (K - 1 - c > 0) s += L[K - 1 - c];
-                    if (c > 0) s += Rr[c];
-                    hs[c] = s;
-                }
+#ifdef LK_SPLIT_ABL_S   /* timing-only ablation build: no horizontal sums */
+            hs[0] = r.sb + r.q[0]; hs[1] = r.sa + r.q[NQ - 1];
+            if constexpr (false)
+#endif
+            if constexpr (RODD) {
+                const double shared = split_tree<0, NQ - 1>(r.q);
+                hs[0] = r.sb + shared;
+                hs[1] = shared + r.sa;
+            } else {
+                const double shared = split_tree<1, NQ - 2>(r.q);
+                hs[0] = (r.q[0] + shared) + r.sa;
+                hs[1] = (r.sb + shared) + r.q[NQ - 1];
             }
-            // vertical van Herk / Gil-Werman step at static chunk position KC
-            double S[K];
 #pragma unroll
             for (int c = 0; c < K; ++c) {
                 pre[c] = (KC == 0) ? hs[c] : pre[c] + hs[c];
@@ -439,6 +509,9 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 #pragma unroll
                     for (int c = 0; c < K; ++c) ring[q][c] += ring[q + 1][c];
             }
+        };
+        auto sstore = [&](auto ec, int i, const double (&S)[K]) __attribute__((always_inline)) {
+            constexpr int E = decltype(ec)::value;
             if (i >= 2 * R) {                                // a full vertical window: hand the K sums to the back end
                 double *sp = &s_sums[(i >> 1) & 1][E][f][0];
 #pragma unroll
@@ -448,12 +521,30 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                 }
             }
         };
-        // one step = marched rows i, i + 1 at static chunk positions Q % WIN, (Q + 1) % WIN
+        // one step = marched rows i, i + 1 at static chunk positions Q % WIN, (Q + 1) % WIN: both rows' LDS reads are
+        // issued first and waited for ONCE (the compiler's per-value s_waitcnt ladder costs an issue slot per step of it)
         auto sstep = [&](auto qc, int i) __attribute__((always_inline)) {
             constexpr int Q = decltype(qc)::value;
             SP_STAMP(t0);
-            srow(std::integral_constant<int, Q % WIN>{}, std::integral_constant<int, 0>{}, i);
-            srow(std::integral_constant<int, (Q + 1) % WIN>{}, std::integral_constant<int, 1>{}, i + 1);
+            SRow rA, rB;
+            double SA[K], SB[K];
+            constexpr bool BOTH = WIN <= 15;                 // bigger rings leave no registers for two rows of taps
+            sload(std::integral_constant<int, 0>{}, i, rA);
+            if constexpr (BOTH) sload(std::integral_constant<int, 1>{}, i + 1, rB);
+#ifndef LK_SPLIT_NO_WAIT1
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
+#endif
+            ssum(std::integral_constant<int, Q % WIN>{}, rA, SA);
+            if constexpr (!BOTH) {
+                __builtin_amdgcn_sched_barrier(0);
+                sload(std::integral_constant<int, 1>{}, i + 1, rB);
+#ifndef LK_SPLIT_NO_WAIT1
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+            }
+            ssum(std::integral_constant<int, (Q + 1) % WIN>{}, rB, SB);
+            sstore(std::integral_constant<int, 0>{}, i, SA);
+            sstore(std::integral_constant<int, 1>{}, i + 1, SB);
             SP_STAMP(t1);
             __syncthreads();
             SP_STAMP(t2);
@@ -476,7 +567,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
     }
 #ifdef LK_SPLIT_STAMPS
     if (a.dbg && (threadIdx.x & 63) == 0) {
-        const unsigned wid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * C::NW + wv;
+        const unsigned wid = blockIdx.x * C::NW + wv;
         for (int k = 0; k < 6; ++k) a.dbg[wid * 8 + k] = seg[k];
         a.dbg[wid * 8 + 6] = NS;
         a.dbg[wid * 8 + 7] = wv;

@@ -297,7 +297,9 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
         if (th > cap) th = (int)cap;
     }
     a.th = th;
-    dim3 grid(gx, (a.H + th - 1) / th, pairs);
+    a.gx = gx; a.gy = (a.H + th - 1) / th;
+    if ((long long)a.gx * a.gy * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
+    dim3 grid((unsigned)(a.gx * a.gy * pairs));      // 1-D: the kernel orders the tiles per XCD
 #ifdef LK_SPLIT_STAMPS
     {   // diagnostic build: dump the stamps of the largest launch to $LKFLOW_STAMPS_OUT after the run
         static unsigned long long *dbuf = nullptr; static size_t dn = 0;
