@@ -289,9 +289,6 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         const int xc = min(max(x, 0), W - 1);
         const bool is_out = t >= HL && t < HL + XO && x < W;
         const bool inner_x = x >= 1 && x <= W - 2;
-        const bool clipped_x = (x - R < 0) || (x + R > W - 1);
-        const bool fix_x = is_out && inner_x && clipped_x;      // lanes whose window is clipped horizontally (first / last block)
-        const bool any_fix_x = __builtin_amdgcn_ballot_w64(fix_x) != 0;
         const int s_slot = KH == 1 ? t : 2 * (((t % K) >> 1) * C::SSTR + t / K) + (t & 1);
 
         [[maybe_unused]] UpSel1 us{};
@@ -343,9 +340,8 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         const int vxo = x * 8;
         int sou = 0, sov = 0;                                   // byte offsets of output row r in the u / v strips
 
-        // One step = the output row pair (y, y + 1), y = y0 + 2p even, at static pair parity P2 = p & 1 (tap
-        // buffer; LDS step parity = (p + R) & 1).  FAST: both windows are vertically inside the image, so nothing
-        // but the per-lane column masks is conditional.  Both variants issue the same vector-memory instructions,
+        // One step = the output row pair (y, y + 1), y = y0 + 2p even, at static pair position P2 = p mod TD (tap
+        // slot; LDS step parity = (p + R) & 1).  Straight-line: every vector-memory instruction is issued
         // unconditionally (see the file header); the two solves are independent and interleave.
         const int vo_lane = is_out ? vxo : (int)0x80000000;   // out of range: the store is dropped
         auto solve5 = [&](const double (&S)[5], bool inner, double &u, double &v) __attribute__((always_inline)) {
@@ -360,26 +356,13 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             u = nz ? qu : 0.0;
             v = nz ? qv : 0.0;
         };
-        auto solve_row = [&](auto fastc, int y, const double (&S)[5], double &u, double &v) __attribute__((always_inline)) {
-            constexpr bool FAST = decltype(fastc)::value;
-            bool inner, fix;
-            if constexpr (FAST) {
-                inner = inner_x;
-                fix = any_fix_x && fix_x;
-            } else {
-                inner = y >= 1 && y <= H - 2 && inner_x;
-                fix = is_out && inner && ((y - R < 0) || (y + R > H - 1) || clipped_x);
-            }
-            solve5(S, inner, u, v);
-            if (fix) {                                      // SerialPyr.cpp:94-95: partial window -> m(y,x) * WIN^2 (rare lanes: redone)
-                double pc[5];
-                lk_products_at(a.i1.at(pair), a.i2.at(pair), a.i1.pitch, H, W, y, x, pc);
-#pragma unroll
-                for (int f = 0; f < 5; ++f) pc[f] = pc[f] * (double)(WIN * WIN);
-                solve5(pc, inner, u, v);
-            }
+        // (pixels whose window is clipped by the image border get m(y,x) * WIN^2 instead of a window sum,
+        // SerialPyr.cpp:94-95: lk_border_kernel overwrites them after this kernel -- a load under a condition in
+        // this loop would make hipcc's vmcnt counting conservative and drain the wave's stores at every step)
+        auto solve_row = [&](int y, const double (&S)[5], double &u, double &v) __attribute__((always_inline)) {
+            solve5(S, inner_x && y >= 1 && y <= H - 2, u, v);
         };
-        auto bpair = [&](auto pc2, auto fastc, int p) __attribute__((always_inline)) {
+        auto bpair = [&](auto pc2, int p) __attribute__((always_inline)) {
             constexpr int P2 = decltype(pc2)::value;        // p mod TD
             constexpr int SPB = (P2 + R) & 1;
             constexpr int TN = (P2 + TD - 1) % TD;          // the slot this pair's own taps just left
@@ -394,8 +377,8 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 #pragma unroll
             for (int f = 0; f < 5; ++f) { S0[f] = s_sums[SPB][0][f][s_slot]; S1[f] = s_sums[SPB][1][f][s_slot]; }
             double ue, ve, uo, vo;
-            solve_row(fastc, y, S0, ue, ve);
-            solve_row(fastc, y + 1, S1, uo, vo);
+            solve_row(y, S0, ue, ve);
+            solve_row(y + 1, S1, uo, vo);
             if constexpr (HAS_UP) {
                 {                                           // even row: rotate in the coarse row turned into slot 0 last pair
                     const double nu = hu[0], nv = hv[0];
@@ -421,8 +404,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         };
         auto bstep = [&](auto pc2, int p) __attribute__((always_inline)) {
             SP_STAMP(t0);
-            if (H >= 2 * R + 2 && (unsigned)(y0 + 2 * p - R) <= (unsigned)(H - 2 - 2 * R)) bpair(pc2, std::true_type{}, p);
-            else bpair(pc2, std::false_type{}, p);
+            bpair(pc2, p);
             SP_STAMP(t1);
             __syncthreads();
             SP_STAMP(t2);
@@ -573,6 +555,45 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         a.dbg[wid * 8 + 7] = wv;
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Clipped-window pixels of lk_split_kernel's output (SerialPyr.cpp:94-95: a pixel inside the outermost ring whose
+// WIN x WIN window leaves the image takes m(y,x) * WIN^2 for each of the five sums): the frame of width R just
+// inside the image, one thread per pixel, launched after lk_split_kernel on the same stream.  Same expressions as
+// the one-role kernels' clipped branch (lk_products_at, lk_solve, pyrup_at).
+// ------------------------------------------------------------------------------------------------
+template <bool HAS_UP>
+__global__ __launch_bounds__(256) void lk_border_kernel(LKArgs a, int win)
+{
+    const int R = win / 2, H = a.H, W = a.W, pair = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    int y, x;
+    const int nr = min(2 * R, H);                            // rows of the top + bottom bands
+    if (idx < (long long)nr * W) {
+        const int k = (int)(idx / W);
+        x = (int)(idx % W);
+        y = (H <= 2 * R) ? k : (k < R ? k : H - 2 * R + k);
+    } else {                                                 // left + right bands of the rows in between
+        const long long k2 = idx - (long long)nr * W;
+        const int nc = min(2 * R, W);
+        if (H <= 2 * R || k2 >= (long long)(H - 2 * R) * nc) return;
+        y = R + (int)(k2 / nc);
+        const int c = (int)(k2 % nc);
+        x = (W <= 2 * R) ? c : (c < R ? c : W - 2 * R + c);
+    }
+    if (!(y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2)) return;                          // outermost ring: 0 (+ pyrUp), done by the main kernel
+    if (!((y - R < 0) || (y + R > H - 1) || (x - R < 0) || (x + R > W - 1))) return;      // full window: done by the main kernel
+    double S[5], u, v;
+    lk_products_at(a.i1.at(pair), a.i2.at(pair), a.i1.pitch, H, W, y, x, S);
+    for (int f = 0; f < 5; ++f) S[f] = S[f] * (double)(win * win);
+    lk_solve(S, u, v);
+    if (HAS_UP) {
+        u += pyrup_at(a.cu.at(pair), a.cu.pitch, H >> 1, W >> 1, y, x);
+        v += pyrup_at(a.cv.at(pair), a.cv.pitch, H >> 1, W >> 1, y, x);
+    }
+    a.u.at(pair)[(long long)y * a.u.pitch + x] = u;
+    a.v.at(pair)[(long long)y * a.v.pitch + x] = v;
 }
 
 }  // namespace lk

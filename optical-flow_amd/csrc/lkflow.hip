@@ -319,6 +319,13 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
 #endif
     if (has_up) hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true>), grid, dim3(C::NT), 0, s, a);
     else hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, false>), grid, dim3(C::NT), 0, s, a);
+    {   // the frame of clipped-window pixels (SerialPyr.cpp:94-95), overwritten in stream order
+        const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
+        const long long n = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
+        dim3 bg((unsigned)((n + 255) / 256), pairs);
+        if (has_up) hipLaunchKernelGGL((lk::lk_border_kernel<true>), bg, dim3(256), 0, s, a, WIN);
+        else hipLaunchKernelGGL((lk::lk_border_kernel<false>), bg, dim3(256), 0, s, a, WIN);
+    }
     return LKFLOW_OK;
 }
 
