@@ -57,6 +57,14 @@
 #define SP_ACC(k, a, b)
 #endif
 
+#ifdef LK_SPLIT_ABL_RAWBAR   /* timing-only ablation build: barrier without the LDS write drain (results are wrong) */
+#define SP_BARRIER() __builtin_amdgcn_s_barrier()
+#elif defined(LK_SPLIT_ABL_NOBAR) /* timing-only ablation build: no barrier in the role loops at all (results are wrong) */
+#define SP_BARRIER() asm volatile("" ::: "memory")
+#else
+#define SP_BARRIER() __syncthreads()
+#endif
+
 namespace lk {
 
 typedef double lk_d2 __attribute__((ext_vector_type(2)));
@@ -268,7 +276,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             asm volatile("" :: "v"(cl[0]), "v"(ca[0]), "v"(cb[0]), "v"(cl[1]), "v"(ca[1]), "v"(cb[1]));
 #endif
             SP_STAMP(t1);
-            __syncthreads();
+            SP_BARRIER();
             SP_STAMP(t2);
             SP_ACC(0, t0, t1); SP_ACC(3, t1, t2);
         };
@@ -406,7 +414,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             SP_STAMP(t0);
             bpair(pc2, p);
             SP_STAMP(t1);
-            __syncthreads();
+            SP_BARRIER();
             SP_STAMP(t2);
             SP_ACC(1, t0, t1); SP_ACC(3, t1, t2);
         };
@@ -528,7 +536,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             sstore(std::integral_constant<int, 0>{}, i, SA);
             sstore(std::integral_constant<int, 1>{}, i + 1, SB);
             SP_STAMP(t1);
-            __syncthreads();
+            SP_BARRIER();
             SP_STAMP(t2);
             SP_ACC(0, t0, t1); SP_ACC(3, t1, t2);
         };
