@@ -296,6 +296,31 @@ def host_call_rate(ctx, cols, rows, levels, win, reps=5):
                          "note": "LKFLOW_OPT_PIN_HOST: the same (re-used) host arrays page-locked in place"}
     finally:
         ctx.pin_host(False)
+    # two engines, pairs alternating between them: pair k's download overlaps pair k+1's upload and kernels
+    import lkflow_amd as lkf
+    eng = [lkf.Context(ctx.device) for _ in range(2)]
+    outs = [(np.empty((rows, cols)), np.empty((rows, cols))) for _ in range(2)]
+    try:
+        for e in eng:
+            e.pin_host(True)
+        for k in range(2):
+            eng[k].enqueue_pair(a8, b8, levels, win, out=outs[k]); eng[k].wait()
+        n = 4 * reps
+        t0 = time.perf_counter()
+        for k in range(n):
+            e = eng[k & 1]
+            e.wait()
+            e.enqueue_pair(a8, b8, levels, win, out=outs[k & 1])
+        for e in eng:
+            e.wait()
+        dt = (time.perf_counter() - t0) / n
+        out["two_engines_u8_pinned"] = {"ms_per_pair": round(dt * 1e3, 3), "Mpixels_per_s": round(rows * cols / dt / 1e6, 1),
+                                        "note": "lkflow_enqueue_pair_u8 alternating between two contexts (throughput of a host-side "
+                                                "video loop, not the latency of one pair)"}
+    finally:
+        for e in eng:
+            e.pin_host(False)
+            e.close()
     return out
 
 

@@ -86,6 +86,13 @@ bool hip_ok(lkflow_ctx *ctx, hipError_t e, const char *what)
     if (ctx) ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
     return false;
 }
+// Release one LKFLOW_OPT_PIN_HOST registration.  A range that another context (or the caller) registered or released
+// in the meantime makes the runtime report an error; it must not stay behind as the thread's sticky "last error",
+// where the next unrelated HIP call of the caller would find it.
+inline void unpin_host_range(void *p)
+{
+    if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+}
 #define HIP_TRY(ctx, call)                                   \
     do {                                                     \
         if (!hip_ok((ctx), (call), #call)) return LKFLOW_E_HIP; \
@@ -579,7 +586,7 @@ void lkflow_ctx_destroy(lkflow_ctx *ctx)
     (void)hipDeviceSynchronize();
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->stage) (void)hipFree(ctx->stage);
-    for (auto &q : ctx->pins) (void)hipHostUnregister(q.p);
+    for (auto &q : ctx->pins) unpin_host_range(q.p);
     for (auto &r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -608,7 +615,7 @@ int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value)
                 if (set_device(ctx)) return LKFLOW_E_HIP;
                 (void)hipStreamSynchronize(ctx->own_stream);
                 ctx->host_inflight = false;
-                for (auto &q : ctx->pins) (void)hipHostUnregister(q.p);
+                for (auto &q : ctx->pins) unpin_host_range(q.p);
                 ctx->pins.clear();
             }
             ctx->pin_host = value;
@@ -810,7 +817,7 @@ static void pin_host_range(lkflow_ctx *ctx, const void *ptr, size_t n)
     for (auto &q : ctx->pins)
         if (p >= q.p && p + n <= q.p + q.n) return;
     if (ctx->pins.size() >= 16) {                            // oldest out
-        (void)hipHostUnregister(ctx->pins.front().p);
+        unpin_host_range(ctx->pins.front().p);
         ctx->pins.erase(ctx->pins.begin());
     }
     if (hipHostRegister(p, n, hipHostRegisterDefault) == hipSuccess) ctx->pins.push_back({p, n});

@@ -126,3 +126,33 @@ def test_u8_and_async_host_entry_points(gpu_ctx, lkflow, oracle, table_u8, golde
     assert np.array_equal(us, u) and np.array_equal(vs, v)
     with pytest.raises(lkflow.LKFlowError):
         gpu_ctx.computeFlow_u8(a8, b8, 8, 3)           # more levels than getMaxLayer
+
+
+def test_two_contexts_pinning_the_same_host_buffers(lkflow, oracle, table_u8, torch):
+    """LKFLOW_OPT_PIN_HOST from two contexts on the SAME arrays (a loop that alternates between two engines): results
+    unchanged, and a registration one context could not take or release must not stay behind as the thread's sticky
+    HIP error (the next torch call would raise it)."""
+    a8, b8 = table_u8
+    a, b = oracle.u8_to_f64(a8), oracle.u8_to_f64(b8)
+    with lkflow.Context(0) as c0:
+        ref = c0.computeFlow(a, b, 7, 3)
+    outs = [(np.empty_like(a), np.empty_like(a)) for _ in range(2)]
+    eng = [lkflow.Context(0) for _ in range(2)]
+    try:
+        for e in eng:
+            e.pin_host(True)
+        for k in range(6):
+            e = eng[k & 1]
+            e.wait()
+            e.enqueue_pair(a8 if k % 3 else a, b8 if k % 3 else b, 7, 3, out=outs[k & 1])
+        for e in eng:
+            e.wait()
+        for u, v in outs:
+            assert np.array_equal(u, ref[0]) and np.array_equal(v, ref[1])
+    finally:
+        for e in eng:
+            e.pin_host(False)
+            e.close()
+    x = torch.ones(1024, device="cuda") * 2          # any HIP call of the caller after it
+    torch.cuda.synchronize()
+    assert float(x.sum()) == 2048.0
