@@ -383,7 +383,11 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             }
             double S0[5], S1[5];
 #pragma unroll
+#ifdef LK_SPLIT_ABL_NOBLDS
+            for (int f = 0; f < 5; ++f) { S0[f] = (double)(p + f); S1[f] = (double)(p - f) + 0.5; }
+#else
             for (int f = 0; f < 5; ++f) { S0[f] = s_sums[SPB][0][f][s_slot]; S1[f] = s_sums[SPB][1][f][s_slot]; }
+#endif
             double ue, ve, uo, vo;
             solve_row(y, S0, ue, ve);
             solve_row(y + 1, S1, uo, vo);
@@ -502,6 +506,9 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         };
         auto sstore = [&](auto ec, int i, const double (&S)[K]) __attribute__((always_inline)) {
             constexpr int E = decltype(ec)::value;
+#ifdef LK_SPLIT_ABL_NOSWR
+            if (S[0] == 12345.678)
+#endif
             if (i >= 2 * R) {                                // a full vertical window: hand the K sums to the back end
                 double *sp = &s_sums[(i >> 1) & 1][E][f][0];
 #pragma unroll
