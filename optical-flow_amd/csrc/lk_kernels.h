@@ -4,6 +4,8 @@
 //   pyrdown_kernel        a2   cv::pyrDown of n planes (row-marching, DPP neighbour taps)
 //   pyrup_kernel          a9   cv::pyrUp (stage entry point / tests; the pipeline fuses it)
 //   warp_kernel           a9+a10+a11  pyrUp(flow) -> float map -> fixed-point bilinear remap (1x4 strips)
+//   lk_split_kernel<WIN>  a3..a8  the same, wave-specialised (front / window-sum / back waves): windows 5..31  (lk_split.h)
+//   lk_border_kernel      a5      clipped-window pixels (m(y,x) * win^2) after lk_split_kernel  (lk_split.h)
 //   lk_march3_kernel<WIN> a3..a8  derivatives, products, win x win sums, 2x2 solve, += pyrUp(flow)  (lk_march3.h)
 //   lk_w3x2_kernel        a3..a8  3 x 3 windows, two columns per lane, no LDS  (lk_w3x2.h)
 //   lk_w3x2f_kernel       a9..a12 + a3..a8  3 x 3 windows: warp fused into the LK kernel  (lk_w3x2f.h)

@@ -4,23 +4,24 @@
 //
 // Why: the one-role kernel (lk_march3.h) keeps the (WIN-1) x 5 vertical ring of a column in ONE wave's
 // registers (140 of 256 VGPRs at 15 x 15 -> 2 waves per SIMD) and sums every horizontal window out of LDS
-// with R+1 reads per pixel and field.  Its ISA shows 19 ds_read2_b64 + 6 LDS stores per marched row and wave =
-// ~220 LDS-pipe cycles, more than its 161 VALU instructions cost a SIMD, and a wave issues at most one
-// instruction of ANY kind per 4 cycles, so its ~410 instructions per row are a >= 1640-cycle serial chain.
-// Here a block of K*64 columns is marched by three kinds of waves, each with a short instruction stream:
+// with R+1 reads per pixel and field; a wave issues at most one instruction of any kind per ~5 cycles, so its
+// ~410 instructions per row are a serial chain of its own, with one other wave per SIMD to fill the gaps.
+// Here a block of 126 columns is marched by 8 waves in three roles, each with a short instruction stream:
 //
 //   * one "F" (front) wave, TWO adjacent columns per lane: image rows (ONE 16-byte load of the pair per image
 //     and row, PF rows in flight, previous row in registers; the left derivative tap is the left lane's second
 //     pixel by a DPP wave shift -- lane 0 is a halo pair, so the wave feeds 126 columns) -> fx, fy, ft -> the
-//     five products of both columns -> ONE ds_write_b128 per field.
-//   * 5 "S" waves, one FIELD each, K adjacent columns per lane: the lane reads the raw products of columns
-//     [K*j - R, K*j + K-1 + R] as aligned 16-byte LDS reads (10 ds_read_b128 at K = 4, R = 7: 2.5 per output
-//     instead of 8 reads), forms the K horizontal windows with a shared core sum (21 adds for 4 outputs at
-//     15 x 15, additions only), runs the vertical van Herk / Gil-Werman ring for its K columns in registers
-//     ((WIN-1) x K x 2 = 112 VGPRs at 15 x 15) and hands the K window sums back through LDS (16-byte stores).
-//   * K "B" (back) waves, one column per lane: the five window sums of a row come back from LDS (one
-//     ds_read_b64 per field) -> clipped-window rule, 2 x 2 solve with true fp64 divisions, /0 -> 0,
-//     "+= pyrUp(coarse flow)" from register-carried coarse rows (taps fetched two rows ahead), streaming store.
+//     five products of both columns (one ds_write_b128 per field) and their pair sums (one ds_write_b64).
+//     Runs at raised wave priority: it is the one wave that feeds the block from memory.
+//   * 5 "S" waves, one FIELD each, two adjacent columns per lane: both horizontal windows of the pair are the
+//     R pair sums they share plus one single product each (R + 2 eight-byte LDS reads, R + 1 additions per row at
+//     odd R), then the vertical van Herk / Gil-Werman ring for the two columns in registers ((WIN-1) x 2 x 2 = 56
+//     VGPRs at 15 x 15), chunks anchored to absolute image rows (results do not depend on the strip height);
+//     the two window sums go back through LDS (one 16-byte store).
+//   * 2 "B" (back) waves, one column per lane: the five window sums of a row come back from LDS (one
+//     ds_read_b64 per field) -> 2 x 2 solve with true fp64 divisions, /0 -> 0, "+= pyrUp(coarse flow)" from
+//     register-carried coarse rows (taps fetched one step ahead), streaming store.  Pixels whose window is
+//     clipped by the image border are overwritten afterwards by lk_border_kernel (end of this file).
 //
 // The three stages run concurrently on different marched rows with double-buffered LDS planes; a pipeline STEP is
 // TWO marched rows (F: rows 2s, 2s+1; S: the two rows of step s-1; B: those of step s-2) and ends in ONE workgroup
@@ -28,14 +29,15 @@
 // and a B wave interleaves the two independent solves of its row pair.  Every vector-memory instruction is
 // issued unconditionally (clamped rows; a store that must not happen gets an out-of-range buffer offset, which
 // the hardware drops): hipcc's s_waitcnt counting gives up on loads or stores under a condition and then drains
-// vmcnt(0) at every use, which serialises a step behind its own prefetch.
-// K = 4 up to 15 x 15 (11 waves, <= 168 VGPRs: 3 waves per SIMD); K = 2 for bigger windows (8 waves), whose
-// ring would not fit a wave at K = 4.
+// vmcnt(0) at every use, which serialised a step behind its own prefetch (F) and behind its own stores (B).
+// <= 128 VGPRs up to 21 x 21: four waves per SIMD = TWO blocks per CU, whose phases interleave (one block per CU
+// marches in lock-step: every wave reads LDS, computes and writes at the same time).  1-D grid, XCD-aware tile
+// order (column blocks of a strip and vertically adjacent strips share halo lines through one L2).
 //
-// Summation order: horizontal = tree over the shared core + short left/right chains, vertical = van Herk; only
-// additions (flat regions give exactly 0 like the reference); same products, solve and pyrUp expressions as
-// lk_march3.h.  Host-checked: W even, H > R + PF + 1, even strip height (a step's row pair is an even and an odd
-// output row); other shapes take lk_march3.h.
+// Only additions in the window sums (flat regions give exactly 0 like the reference); same products, solve and pyrUp
+// expressions as lk_march3.h.  Host-checked: W and H even, H > R + PF + 1, even strip height (a step's row pair is an
+// even and an odd output row); other shapes take lk_march3.h.  -DLK_SPLIT_STAMPS / -DLK_SPLIT_ABL_* are diagnostic
+// builds (per-role cycle stamps; timing-only ablations whose results are wrong by design) -- see DESIGN.md section 4.
 #pragma once
 #include "lk_w3x2.h"     // buf_ld2 (16-byte buffer loads), lk_march3.h
 
