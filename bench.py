@@ -458,10 +458,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        tmo = datetime.timedelta(seconds=300)                # a stuck rank aborts the job instead of hanging the node
         if rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
 
     cols, rows, levels, win, p_default = CONFIGS[args.config]
     win = args.win or win
@@ -547,10 +549,13 @@ def main():
         dt = t.item()
 
     stream_extra = None
-    if dist is not None and not args.no_extras:
+    if dist is not None and not args.no_extras and os.environ.get("LKFLOW_BENCH_NO_STREAM_EXTRA") != "1":
         del prev, nxt, U, V
         torch.cuda.empty_cache()
-        stream_extra = stream_sharding_extra(lkf, torch, dist, synth, ctx, args.config, dev, rank, world)
+        try:
+            stream_extra = stream_sharding_extra(lkf, torch, dist, synth, ctx, args.config, dev, rank, world)
+        except Exception as e:                               # noqa: BLE001 -- an extra must never cost the headline line
+            stream_extra = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
         prev = nxt = U = V = None
 
     if rank == 0:
