@@ -461,10 +461,10 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 #pragma unroll
         for (int c = 0; c < K; ++c) pre[c] = 0.0;
 
-        auto sload = [&](auto ec, int i, SRow &r) __attribute__((always_inline)) {
-            constexpr int E = decltype(ec)::value;
-            const double *qq = &s_q[(i >> 1) & 1][E][f][PADJ + j];
-            const double *pp = &s_prod[(i >> 1) & 1][E][f][2 * (PADJ + j)];
+        auto sload = [&](auto spc, auto ec, SRow &r) __attribute__((always_inline)) {
+            constexpr int SPP = decltype(spc)::value, E = decltype(ec)::value;   // LDS plane (step parity), row of the step
+            const double *qq = &s_q[SPP][E][f][PADJ + j];
+            const double *pp = &s_prod[SPP][E][f][2 * (PADJ + j)];
 #ifdef LK_SPLIT_ABL_NOSLDS
 #pragma unroll
             for (int d = 0; d < NQ; ++d) r.q[d] = (double)(i + d);
@@ -506,13 +506,15 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                     for (int c = 0; c < K; ++c) ring[q][c] += ring[q + 1][c];
             }
         };
-        auto sstore = [&](auto ec, int i, const double (&S)[K]) __attribute__((always_inline)) {
-            constexpr int E = decltype(ec)::value;
+        // (rows before the first full vertical window are stored too: B reads a sums plane only from marched row 2R on,
+        // by which time every plane has been overwritten with real sums -- an unconditional store costs no test)
+        auto sstore = [&](auto spc, auto ec, const double (&S)[K]) __attribute__((always_inline)) {
+            constexpr int SPP = decltype(spc)::value, E = decltype(ec)::value;
 #ifdef LK_SPLIT_ABL_NOSWR
             if (S[0] == 12345.678)
 #endif
-            if (i >= 2 * R) {                                // a full vertical window: hand the K sums to the back end
-                double *sp = &s_sums[(i >> 1) & 1][E][f][0];
+            {
+                double *sp = &s_sums[SPP][E][f][0];
 #pragma unroll
                 for (int h = 0; h < KH; ++h) {
                     lk_d2 o; o.x = S[2 * h]; o.y = S[2 * h + 1];
@@ -520,30 +522,34 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                 }
             }
         };
-        // one step = marched rows i, i + 1 at static chunk positions Q % WIN, (Q + 1) % WIN: both rows' LDS reads are
-        // issued first and waited for ONCE (the compiler's per-value s_waitcnt ladder costs an issue slot per step of it)
-        auto sstep = [&](auto qc, int i) __attribute__((always_inline)) {
-            constexpr int Q = decltype(qc)::value;
+        // one step = two marched rows at static position T of the unrolled body: chunk positions 2T % WIN and
+        // (2T + 1) % WIN, LDS plane T & 1.  Both rows' LDS reads are issued first (windows up to 15 x 15).
+        auto sstep = [&](auto tc) __attribute__((always_inline)) {
+            constexpr int T = decltype(tc)::value;
+            constexpr int Q = (2 * T) % WIN;
+            using SPc = std::integral_constant<int, T & 1>;
+            using E0 = std::integral_constant<int, 0>;
+            using E1 = std::integral_constant<int, 1>;
             SP_STAMP(t0);
             SRow rA, rB;
             double SA[K], SB[K];
             constexpr bool BOTH = WIN <= 15;                 // bigger rings leave no registers for two rows of taps
-            sload(std::integral_constant<int, 0>{}, i, rA);
-            if constexpr (BOTH) sload(std::integral_constant<int, 1>{}, i + 1, rB);
+            sload(SPc{}, E0{}, rA);
+            if constexpr (BOTH) sload(SPc{}, E1{}, rB);
 #ifndef LK_SPLIT_NO_WAIT1
             __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
 #endif
-            ssum(std::integral_constant<int, Q % WIN>{}, rA, SA);
+            ssum(std::integral_constant<int, Q>{}, rA, SA);
             if constexpr (!BOTH) {
                 __builtin_amdgcn_sched_barrier(0);
-                sload(std::integral_constant<int, 1>{}, i + 1, rB);
+                sload(SPc{}, E1{}, rB);
 #ifndef LK_SPLIT_NO_WAIT1
                 __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
             }
             ssum(std::integral_constant<int, (Q + 1) % WIN>{}, rB, SB);
-            sstore(std::integral_constant<int, 0>{}, i, SA);
-            sstore(std::integral_constant<int, 1>{}, i + 1, SB);
+            sstore(SPc{}, E0{}, SA);
+            sstore(SPc{}, E1{}, SB);
             SP_STAMP(t1);
             SP_BARRIER();
             SP_STAMP(t2);
@@ -553,14 +559,17 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         // The van Herk chunks are anchored to ABSOLUTE image rows (chunk position of image row r = r mod WIN), so the
         // order in which a window's rows are added belongs to the output row, not to the strip: results do not depend
         // on the strip height the launcher picks from the batch size (sharded == unsharded bit for bit).
-        // The unrolled body holds WIN steps; step Qs works at chunk positions (2Qs % WIN, (2Qs + 1) % WIN), which visit
-        // every residue (WIN is odd), so the march enters the body at the step whose first row has position kc0.
+        // The unrolled body holds 2 WIN steps (every chunk position of a row pair with either LDS plane, all static);
+        // the march enters it at the step T0 whose first row has chunk position kc0 and whose plane is 0:
+        // 2 T0 = kc0 (mod WIN), T0 even.  One counter test per step.
         const int kc0 = ((yy0 % WIN) + WIN) % WIN;           // chunk position of marched row 0
-        const int qs0 = (kc0 & 1) ? (kc0 + WIN) / 2 : kc0 / 2;
-        for (int base = 0; base < qs0 + nsw; base += WIN) {
-            [&]<int... Qs>(std::integer_sequence<int, Qs...>) __attribute__((always_inline)) {
-                ((base + Qs >= qs0 && base + Qs < qs0 + nsw ? (sstep(std::integral_constant<int, 2 * Qs>{}, 2 * (base + Qs - qs0)), 0) : 0), ...);
-            }(std::make_integer_sequence<int, WIN>{});
+        int t0s = (kc0 & 1) ? (kc0 + WIN) / 2 : kc0 / 2;     // 2 t0s = kc0 (mod WIN), 0 <= t0s < WIN
+        if (t0s & 1) t0s += WIN;                             // WIN is odd: the other solution is even
+        int cnt = -t0s;                                      // work step number of body position 0 in the first pass
+        for (; cnt < nsw; ) {
+            [&]<int... Ts>(std::integer_sequence<int, Ts...>) __attribute__((always_inline)) {
+                (((unsigned)cnt < (unsigned)nsw ? (sstep(std::integral_constant<int, Ts>{}), 0) : 0, ++cnt), ...);
+            }(std::make_integer_sequence<int, 2 * WIN>{});
         }
         for (int k = nsw + 1; k < NS; ++k) __syncthreads(); // remaining steps: only the back end works / idle tail
     }
