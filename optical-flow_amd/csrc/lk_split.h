@@ -11,11 +11,12 @@
 //   * one "F" (front) wave, TWO adjacent columns per lane: image rows (ONE 16-byte load of the pair per image
 //     and row, PF rows in flight, previous row in registers; the left derivative tap is the left lane's second
 //     pixel by a DPP wave shift -- lane 0 is a halo pair, so the wave feeds 126 columns) -> fx, fy, ft -> the
-//     five products of both columns (one ds_write_b128 per field) and their pair sums (one ds_write_b64).
-//     Runs at raised wave priority: it is the one wave that feeds the block from memory.
+//     five products of both columns (one ds_write_b128 per field).  Runs at raised wave priority: it is the one
+//     wave that feeds the block from memory, and it has the longest instruction stream of the three roles.
 //   * 5 "S" waves, one FIELD each, two adjacent columns per lane: both horizontal windows of the pair are the
-//     R pair sums they share plus one single product each (R + 2 eight-byte LDS reads, R + 1 additions per row at
-//     odd R), then the vertical van Herk / Gil-Werman ring for the two columns in registers ((WIN-1) x 2 x 2 = 56
+//     R pair sums they share plus one single product each (R 16-byte LDS reads of column pairs, summed here,
+//     + 2 eight-byte reads, 2R + 1 additions per row at odd R; -DLK_SPLIT_QSUM=1: F publishes the pair sums
+//     instead), then the vertical van Herk / Gil-Werman ring for the two columns in registers ((WIN-1) x 2 x 2 = 56
 //     VGPRs at 15 x 15), chunks anchored to absolute image rows (results do not depend on the strip height);
 //     the two window sums go back through LDS (one 16-byte store).
 //   * 2 "B" (back) waves, one column per lane: the five window sums of a row come back from LDS (one
@@ -96,6 +97,11 @@ struct SplitCfg {
 #else
     static constexpr int WPE = (K == 2 && WIN <= 21) ? 4 : 1;   // waves per SIMD to compile for (8-wave blocks: 4 -> two blocks per CU)
 #endif
+#ifdef LK_SPLIT_QSUM
+    static constexpr bool QSUM = LK_SPLIT_QSUM != 0;
+#else
+    static constexpr bool QSUM = false;              // F publishes the pair sums a + b (true) or S adds the raw pairs itself (false)
+#endif
     static constexpr int UN = PF >= 4 ? PF / 2 : 2;  // unrolled F group in steps: even (LDS buffer parity) and PF rows (queue slots)
     static_assert(K == 2, "one F wave feeds 126 columns: S lanes own 2 columns (K = 4 ran one 11-wave block per CU: slower)");
     static_assert(PSTR >= NJP, "product half-planes must not overlap");
@@ -119,7 +125,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
     using C = SplitCfg<WIN, K>;
     constexpr int R = C::R, TXC = C::TXC, XO = C::XO, KH = C::KH, PADJ = C::PADJ, PF = C::PF, UN = C::UN, HL = C::HL;
     __shared__ __attribute__((aligned(16))) double s_prod[2][2][5][C::PROD_D];   // [step parity][row of the step][field]: (a, b) products of every column pair
-    __shared__ double s_q[2][2][5][C::NJP];                                       // the pair sums a + b (index = chunk)
+    __shared__ double s_q[C::QSUM ? 2 : 1][C::QSUM ? 2 : 1][C::QSUM ? 5 : 1][C::QSUM ? C::NJP : 1];   // the pair sums a + b (index = chunk), if F publishes them
     __shared__ __attribute__((aligned(16))) double s_sums[2][2][5][C::SUMS_D];
 
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -156,7 +162,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
         const int chunk = h * C::PSTR + (side ? PADJ + 63 + pj : min(pj, PADJ - 1));
         s_prod[b >> 1][b & 1][f][2 * chunk] = 0.0;
         s_prod[b >> 1][b & 1][f][2 * chunk + 1] = 0.0;
-        s_q[b >> 1][b & 1][f][chunk] = 0.0;
+        if constexpr (C::QSUM) s_q[b >> 1][b & 1][f][chunk] = 0.0;
     }
     __syncthreads();
 
@@ -254,7 +260,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                 if (xa_ == 12345.678) s_q[SP][E][FI][p_chunk] = xa_ + xb_;
 #else
                 *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][FI][2 * p_chunk]) = o;
-                s_q[SP][E][FI][p_chunk] = xa_ + xb_;
+                if constexpr (C::QSUM) s_q[SP][E][FI][p_chunk] = xa_ + xb_;
 #endif
             };
             put(std::integral_constant<int, 0>{}, fxa * fxa, fxb * fxb);
@@ -463,8 +469,18 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 
         auto sload = [&](auto spc, auto ec, SRow &r) __attribute__((always_inline)) {
             constexpr int SPP = decltype(spc)::value, E = decltype(ec)::value;   // LDS plane (step parity), row of the step
-            const double *qq = &s_q[SPP][E][f][PADJ + j];
             const double *pp = &s_prod[SPP][E][f][2 * (PADJ + j)];
+            if constexpr (!C::QSUM) {                        // the pairs themselves (16-byte reads), summed here: F, the one wave
+#pragma unroll                                               // that feeds the block, has the longest instruction stream
+                for (int d = 0; d < NQ; ++d) {
+                    const lk_d2 c2 = *reinterpret_cast<const lk_d2 *>(pp + 2 * (d - QH));
+                    r.q[d] = c2.x + c2.y;
+                }
+                r.sb = pp[-2 * HS + 1];
+                r.sa = pp[2 * HS];
+                return;
+            }
+            const double *qq = &s_q[C::QSUM ? SPP : 0][C::QSUM ? E : 0][C::QSUM ? f : 0][C::QSUM ? PADJ + j : 0];
 #ifdef LK_SPLIT_ABL_NOSLDS
 #pragma unroll
             for (int d = 0; d < NQ; ++d) r.q[d] = (double)(i + d);
