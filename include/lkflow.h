@@ -81,6 +81,11 @@ int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int 
                                   points move data by asynchronous DMA instead of the pageable path.  ONLY for buffers that
                                   outlive the context or are re-used call after call (a video loop's Mats): a registered
                                   buffer must not be freed while the option is on. */
+#define LKFLOW_OPT_FUSE_WARP 5 /* 0 (default) / 1: windows 5..15 on even levels: the warp runs INSIDE the wave-specialised LK
+                                  kernel (two extra "W" waves per block produce the warped rows straight into LDS), so the
+                                  warped planes never reach memory.  Bit-identical results; measured SLOWER than warp + LK
+                                  on MI355X (10-wave blocks do not pair up on a CU: DESIGN.md section 4), hence opt-in.
+                                  Ignored with LKFLOW_MUTATE_INPUTS at level 0 (the caller wants the warped images). */
 int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value);
 
 /* Stage ids of the kernels the pyramid driver launches (level = pyramid level the launch works at;

@@ -48,6 +48,9 @@
 #ifndef LK_SPLIT_PRIO_F
 #define LK_SPLIT_PRIO_F 3
 #endif
+#ifndef LK_SPLIT_BOTH_MAX
+#define LK_SPLIT_BOTH_MAX 15   /* widest window whose S waves issue the LDS reads of both rows of a step up front */
+#endif
 #ifndef LK_SPLIT_TD
 #define LK_SPLIT_TD 2    /* even: row pairs of coarse taps a B lane keeps in flight (4 spills at 15x15 and is slower) */
 #endif
@@ -72,16 +75,21 @@ namespace lk {
 
 typedef double lk_d2 __attribute__((ext_vector_type(2)));
 
-template <int WIN, int K>
+template <int WIN, int K, bool FW = false>
 struct SplitCfg {
     static constexpr int R = WIN / 2;
+#ifndef LK_SPLIT_IDLE_WAVES
+#define LK_SPLIT_IDLE_WAVES 0    /* diagnostic: extra waves that only take part in the barriers (how do 10-wave blocks share a CU?) */
+#endif
+    static constexpr int NWW = FW ? K : LK_SPLIT_IDLE_WAVES;   // W waves (fused warp): 64 columns each, one column per lane
+    static constexpr int LAG = FW ? 2 : 0;           // pipeline steps the W role runs ahead of F
     static constexpr int PF = LK_SPLIT_PF;           // image rows in flight per F lane: a pipeline step is short, HBM latency is not
     static constexpr int NB = K;                     // B waves: 64 columns each
     static constexpr int NF = 1;                     // one F wave: lane 0 is a halo pair (left tap of lane 1), lanes 1..63 = 126 columns
     static constexpr int TXC = 64 * K - 2;           // columns per block with products
     static constexpr int HL = R + (R & 1);           // halo columns on each side (even: a lane's column pair is 16-byte aligned)
     static constexpr int XO = TXC - 2 * HL;          // output columns per block
-    static constexpr int NW = NB + 5 + NF;           // waves per block, in this order: B, S, F
+    static constexpr int NW = NB + 5 + NF + NWW;     // waves per block, in this order: B, S, F, W
     static constexpr int NT = 64 * NW;
     static constexpr int KH = K / 2;                 // 16-byte chunks (column pairs) per S lane
     static constexpr int PADJ = (R + K - 1) / K;     // pad lanes on each side of a product plane
@@ -95,7 +103,8 @@ struct SplitCfg {
 #ifdef LK_SPLIT_WPE
     static constexpr int WPE = LK_SPLIT_WPE;
 #else
-    static constexpr int WPE = (K == 2 && WIN <= 21) ? 4 : 1;   // waves per SIMD to compile for (8-wave blocks: 4 -> two blocks per CU)
+    // waves per SIMD to compile for (8-wave blocks: 4 -> two blocks per CU; 10-wave blocks with the W role: 5 -> two blocks)
+    static constexpr int WPE = FW ? 5 : ((K == 2 && WIN <= 21) ? 4 : 1);
 #endif
 #ifdef LK_SPLIT_QSUM
     static constexpr bool QSUM = LK_SPLIT_QSUM != 0;
@@ -119,16 +128,32 @@ __device__ __forceinline__ double split_tree(const A &v)
     }
 }
 
-template <int WIN, int K, bool HAS_UP>
-__global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) void lk_split_kernel(LKArgs a)
+template <int WIN, int K, bool HAS_UP, bool FW = false>
+__global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::WPE)) void lk_split_kernel(LKArgs a)
 {
-    using C = SplitCfg<WIN, K>;
+    using C = SplitCfg<WIN, K, FW>;
+    static_assert(!FW || HAS_UP, "the fused warp needs a coarser level");
     constexpr int R = C::R, TXC = C::TXC, XO = C::XO, KH = C::KH, PADJ = C::PADJ, PF = C::PF, UN = C::UN, HL = C::HL;
     __shared__ __attribute__((aligned(16))) double s_prod[2][2][5][C::PROD_D];   // [step parity][row of the step][field]: (a, b) products of every column pair
     __shared__ double s_q[C::QSUM ? 2 : 1][C::QSUM ? 2 : 1][C::QSUM ? 5 : 1][C::QSUM ? C::NJP : 1];   // the pair sums a + b (index = chunk), if F publishes them
     __shared__ __attribute__((aligned(16))) double s_sums[2][2][5][C::SUMS_D];
+    // FW: the warped rows W hands to F: [step parity][row of the step][image][block column - (-2)] (128 columns: F's 64 pairs)
+    __shared__ __attribute__((aligned(16))) double s_w[FW ? 2 : 1][FW ? 2 : 1][FW ? 2 : 1][FW ? 128 : 2];
+    // FW: F's coarse-row service: [step parity][u, v][block column + 2]: the horizontally filtered coarse row W rotates in
+    __shared__ __attribute__((aligned(16))) double s_c[FW ? 2 : 1][FW ? 2 : 1][FW ? 128 : 2];
 
+    // logical wave (role order B, S, F) of the physical wave: the role -> SIMD placement is an A/B knob (-DLK_SPLIT_PERM=...)
+#ifdef LK_SPLIT_PERM
+    constexpr int kPerm[16] = {LK_SPLIT_PERM};
+    const int pw = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int wv_ = 0;
+#pragma unroll
+    for (int q = 0; q < C::NW; ++q) wv_ = (pw == q) ? kPerm[q] : wv_;
+    const int wv = __builtin_amdgcn_readfirstlane(wv_);
+#else
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#endif
+    const int ltid = wv * 64 + ((int)threadIdx.x & 63);   // thread index in role order
 #ifdef LK_SPLIT_STAMPS
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -151,7 +176,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
     const int yy0 = y0 - R;
     const int x0 = bx * XO - HL;                     // image column of block column 0 (even)
     const int nsw = nm / 2;                          // steps in which F (and, one step later, S) has rows
-    const int ns = nsw + 2;                          // pipeline steps: B trails F by two
+    const int ns = nsw + 2 + C::LAG;                 // pipeline steps: B trails F by two (FW: F trails W by two)
     const int NS = (ns + UN - 1) / UN * UN;          // barriers per wave: padded to whole F groups (idle tail steps)
 
     // zero the pad lanes of the product planes once (only non-output columns ever read them)
@@ -166,14 +191,238 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
     }
     __syncthreads();
 
-    if (wv >= C::NB + 5) {
+    // FW: coarse-row bookkeeping shared by the W role and by F's coarse-row service.  A W-step's row pair holds one even
+    // row ye (slot EV; yy0 has R's parity); entering it moves the carried coarse rows s(i-1), s(i), s(i+1) on to
+    // i = ye >> 1 by rotating in s((ye >> 1) + 1) -- unless ye < 2 (rows above the image use row 1's pair) or below the image
+    [[maybe_unused]] constexpr int EV = R & 1;
+    [[maybe_unused]] const int ye0 = yy0 - 2 + EV;                       // the even row of W-step 0
+    [[maybe_unused]] const int ib = ye0 >= 2 ? (ye0 >> 1) - 1 : 0;       // the carried rows start as s(ib-1), s(ib), s(ib+1)
+    [[maybe_unused]] const int c_lo = max(ib - 1, 0);                    // first coarse row the descriptors cover
+    [[maybe_unused]] auto up_srow_w = [&](int k) { const int Hc = H >> 1; return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };
+    [[maybe_unused]] auto rot_row_off = [&](int t) { return max(up_srow_w(((ye0 + 2 * t) >> 1) + 1) - c_lo, 0); };   // row W-step t rotates in
+
+    if (!FW && wv > C::NB + 5) {                     // diagnostic idle waves (LK_SPLIT_IDLE_WAVES)
+        for (int k = 0; k < NS; ++k) __syncthreads();
+    } else if (FW && wv > C::NB + 5) {
+        // =========================================================================================
+        // W waves (fused warp, a9-a12): one column per lane -> the warped rows of both images, through LDS to F
+        // =========================================================================================
+        // cv::pyrUp of the coarse flow (incremental: the three horizontally filtered coarse rows of the current row
+        // pair are carried in registers; the new row of a step comes from F's coarse-row service through LDS), float
+        // map, 1/32-pixel fixed-point bilinear remap with fp64 blend: warp_kernel's arithmetic bit for bit (lk_kernels.h,
+        // lk_device.h remap_bilinear).  W-step t produces the marched rows yy0 - 2 + 2t and yy0 - 1 + 2t into plane
+        // t & 1; F reads them in step t + 1 (so F-step s runs in pipeline step s + 2).  Software pipeline: step t blends
+        // the taps gathered for step t, issues the gathers of step t + 1 (addresses ready since step t - 1) and then
+        // computes the addresses of step t + 2 while they fly.  Gathers are unconditional, from clamped addresses: taps
+        // that fall outside the image are zeroed afterwards (BORDER_CONSTANT 0) in a wave-uniform branch that holds no
+        // memory instruction.
+        const int g = ltid - 64 * (C::NB + 6);       // block column g - 2: the two columns of F lane g >> 1
+        const int Hc = H >> 1, Wc = W >> 1;
+        const int xcol = min(max(x0 + 2 * ((g >> 1) - 1), 0), W - 2) + (g & 1);   // F's clamped column pair
+        const float xf = (float)xcol;
+        const int ipb = (int)a.i1.pitch * 8;         // (host: both images have the same pitch)
+        const long long img_bytes = ((long long)(H - 1) * a.i1.pitch + W) * 8;
+        const __amdgpu_buffer_rsrc_t rI1 = buf_rsrc(a.i1.at(pair), img_bytes);
+        const __amdgpu_buffer_rsrc_t rI2 = buf_rsrc(a.i2.at(pair), img_bytes);
+        double hu[3], hv[3];
+        struct WAddr { int vo[2][2], sx[2][2], sy[2][2]; };
+        // rotation of W-step t with the new coarse row (nu, nv), up-sampled flow of its two rows, map, fixed-point coordinates
+        auto waddr = [&](int t, double nu, double nv, WAddr &A) __attribute__((always_inline)) {
+            const int ye = ye0 + 2 * t;
+            const bool rot = ye >= 2 && ye <= H - 1;
+            double uu[2], vv[2];
+            auto odd_up = [&](int e) __attribute__((always_inline)) {
+                uu[e] = ((hu[1] + hu[2]) * 4) * (1.0 / 64); vv[e] = ((hv[1] + hv[2]) * 4) * (1.0 / 64);
+            };
+            auto even_up = [&](int e) __attribute__((always_inline)) {
+                uu[e] = (hu[0] + hu[1] * 6 + hu[2]) * (1.0 / 64); vv[e] = (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);
+            };
+            if constexpr (EV == 1) odd_up(0);                           // the odd row above the even one: before the rotation
+            if (rot) {
+                hu[0] = hu[1]; hu[1] = hu[2]; hu[2] = nu;
+                hv[0] = hv[1]; hv[1] = hv[2]; hv[2] = nv;
+            }
+            even_up(EV);
+            if constexpr (EV == 0) odd_up(1);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int yy = yy0 - 2 + 2 * t + e;
+                // rows outside the image: only row -1 is ever used (filter2D's reflect-101 tap of row 0) = row 1; the
+                // others feed products that F zeroes, any in-image row will do
+                const float yf = (float)min(yy < 0 ? -yy : yy, H - 1);
+                const float hx = (float)uu[e] / 2, hy = (float)vv[e] / 2;   // map build (ParallelVideoPyr.cpp:674-678), float32
+#pragma unroll
+                for (int im = 0; im < 2; ++im) {
+                    const float mx = im ? xf - hx : xf + hx, my = im ? yf - hy : yf + hy;
+                    const int sx = cv_round_f(mx * 32.0f), sy = cv_round_f(my * 32.0f);
+                    const int ixc = min(max(sat_short(sx >> 5), 0), W - 2), iyc = min(max(sat_short(sy >> 5), 0), H - 2);
+                    A.vo[e][im] = iyc * ipb + ixc * 8;
+                    A.sx[e][im] = sx; A.sy[e][im] = sy;
+                }
+            }
+        };
+        lk_d2 G[2][2][2];                            // gathers in flight: [row of the step][image][tap row] = columns (ixc, ixc + 1)
+        auto wissue = [&](const WAddr &A) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int im = 0; im < 2; ++im) {
+                    const __amdgpu_buffer_rsrc_t rI = im ? rI2 : rI1;
+                    double g0x, g0y, g1x, g1y;
+#ifdef LK_SPLIT_ABL_WNOLOAD   /* timing-only ablation build: no gathers (results are wrong) */
+                    g0x = g1y = (double)A.vo[e][im]; g0y = g1x = 1.0; (void)rI;
+#else
+                    buf_ld2(rI, A.vo[e][im], 0, g0x, g0y);
+                    buf_ld2(rI, A.vo[e][im], ipb, g1x, g1y);
+#endif
+                    G[e][im][0].x = g0x; G[e][im][0].y = g0y; G[e][im][1].x = g1x; G[e][im][1].y = g1y;
+                }
+        };
+        auto wblend = [&](auto pc, const WAddr &A) __attribute__((always_inline)) {     // blend the gathered taps of a step -> LDS plane
+            constexpr int WP = decltype(pc)::value;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int im = 0; im < 2; ++im) {
+                    const int sx = A.sx[e][im], sy = A.sy[e][im];
+                    const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
+                    const int dx = ix - min(max(ix, 0), W - 2), dy = iy - min(max(iy, 0), H - 2);
+                    const float fa = (float)(sx & 31) * (1.0f / 32), fb = (float)(sy & 31) * (1.0f / 32);
+                    const float w0 = (1.0f - fb) * (1.0f - fa), w1 = (1.0f - fb) * fa, w2 = fb * (1.0f - fa), w3 = fb * fa;
+                    lk_d2 top = G[e][im][0], bot = G[e][im][1];
+                    if (__builtin_amdgcn_ballot_w64((dx | dy) != 0) != 0) {   // some lane's taps leave the image (wave-uniform, no memory instruction)
+                        const lk_d2 z = {0.0, 0.0};
+                        const lk_d2 t0 = top, t1 = bot;
+                        top = dy == 0 ? t0 : (dy == 1 ? t1 : z);
+                        bot = dy == 0 ? t1 : (dy == -1 ? t0 : z);
+                        const lk_d2 a0 = top, a1 = bot;
+                        top.x = dx == 0 ? a0.x : (dx == 1 ? a0.y : 0.0); top.y = dx == 0 ? a0.y : (dx == -1 ? a0.x : 0.0);
+                        bot.x = dx == 0 ? a1.x : (dx == 1 ? a1.y : 0.0); bot.y = dx == 0 ? a1.y : (dx == -1 ? a1.x : 0.0);
+                    }
+                    s_w[WP][e][im][g] = top.x * (double)w0 + top.y * (double)w1 + bot.x * (double)w2 + bot.y * (double)w3;
+                }
+        };
+        WAddr cur, nxt;
+        {   // prologue: the carried rows and the rotations of W-steps 0 and 1 straight from memory (from step 2 on: F's service)
+            const UpSel1 us = make_upsel1(xcol, Wc);
+            const int cpub = (int)a.cu.pitch * 8, cpvb = (int)a.cv.pitch * 8;
+            const __amdgpu_buffer_rsrc_t rCU = buf_rsrc(a.cu.at(pair) + (long long)c_lo * a.cu.pitch, ((long long)(Hc - 1 - c_lo) * a.cu.pitch + Wc) * 8);
+            const __amdgpu_buffer_rsrc_t rCV = buf_rsrc(a.cv.at(pair) + (long long)c_lo * a.cv.pitch, ((long long)(Hc - 1 - c_lo) * a.cv.pitch + Wc) * 8);
+            auto srow = [&](int sr, double &su, double &sv) __attribute__((always_inline)) {
+                su = pyrup_h1v(buf_ld(rCU, us.jm, sr * cpub), buf_ld(rCU, us.jc, sr * cpub), buf_ld(rCU, us.jp, sr * cpub), us);
+                sv = pyrup_h1v(buf_ld(rCV, us.jm, sr * cpvb), buf_ld(rCV, us.jc, sr * cpvb), buf_ld(rCV, us.jp, sr * cpvb), us);
+            };
+#pragma unroll
+            for (int q = 0; q < 3; ++q) srow(up_srow_w(ib - 1 + q) - c_lo, hu[q], hv[q]);
+            double nu, nv;
+            srow(rot_row_off(0), nu, nv); waddr(0, nu, nv, cur);
+            wissue(cur);
+            srow(rot_row_off(1), nu, nv); waddr(1, nu, nv, nxt);
+        }
+        __syncthreads();                             // F's service has published the row W-step 2 rotates in
+        auto wstep = [&](auto pc, int t) __attribute__((always_inline)) {
+            constexpr int WP = decltype(pc)::value;
+            wblend(pc, cur);
+            wissue(nxt);
+            cur = nxt;
+            const double nu = s_c[WP ^ 1][0][g], nv = s_c[WP ^ 1][1][g];   // written by F in step t - 1: the row step t + 2 rotates in
+            waddr(t + 2, nu, nv, nxt);
+            SP_BARRIER();
+        };
+        for (int t = 0; t < NS; t += 2) {                               // NS is even
+            wstep(std::integral_constant<int, 0>{}, t);
+            wstep(std::integral_constant<int, 1>{}, t + 1);
+        }
+    } else if (wv >= C::NB + 5) {
         // =========================================================================================
         // F waves: two adjacent columns per lane -> products
         // =========================================================================================
         // the one wave that feeds the block's pipeline from memory issues ahead of the seven that consume (A/B: level-0
         // launch 0.80 -> 0.77 ms; raising B instead, or both, gains nothing)
         __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_F);
-        const int m = (int)threadIdx.x - 64 * (C::NB + 5);   // lane: block columns 2(m-1), 2(m-1)+1; lane 0 = the pair left of the block
+        const int m = ltid - 64 * (C::NB + 5);   // lane: block columns 2(m-1), 2(m-1)+1; lane 0 = the pair left of the block
+      if constexpr (FW) {
+        // fused warp: the rows come from the W waves through LDS (plane (t - 1) & 1 in pipeline step t); F-step s = t - 2.
+        // Steps 0 and 1 run the same code on rows nobody consumes (step 1 leaves row yy0 - 1 behind as the previous row).
+        const int xa = x0 + 2 * (m - 1);
+        const bool col_in = xa >= 0 && xa < W;
+        const bool all_col_in = __builtin_amdgcn_ballot_w64(!col_in) == 0;
+        const int p_chunk = PADJ + m - 1;
+        auto left_tap = [&](double vb) __attribute__((always_inline)) { return dpp_wave_shr1(vb); };
+        // coarse-row service for the W waves: the horizontally filtered coarse row (cv::pyrUp's horizontal pass, both flow
+        // planes, both columns of this lane's pair) that W-step t + 3 rotates in, published in step t; its taps are fetched
+        // one step ahead.  (F has no other memory traffic in this mode, and the W lanes of a pair share their taps.)
+        const int Hc = H >> 1, Wc = W >> 1;
+        const int xc = min(max(xa, 0), W - 2);
+        const UpSel1 usA = make_upsel1(xc, Wc), usB = make_upsel1(xc + 1, Wc);
+        const int cpub = (int)a.cu.pitch * 8, cpvb = (int)a.cv.pitch * 8;
+        const __amdgpu_buffer_rsrc_t rCU = buf_rsrc(a.cu.at(pair) + (long long)c_lo * a.cu.pitch, ((long long)(Hc - 1 - c_lo) * a.cu.pitch + Wc) * 8);
+        const __amdgpu_buffer_rsrc_t rCV = buf_rsrc(a.cv.at(pair) + (long long)c_lo * a.cv.pitch, ((long long)(Hc - 1 - c_lo) * a.cv.pitch + Wc) * 8);
+        double tpf[6];
+        auto svc_load = [&](int t) __attribute__((always_inline)) {     // taps of the row W-step t rotates in
+            const int sr = rot_row_off(t), su = sr * cpub, sv = sr * cpvb;
+            tpf[0] = buf_ld(rCU, usA.jm, su); tpf[1] = buf_ld(rCU, usA.jc, su); tpf[2] = buf_ld(rCU, usA.jp, su);
+            tpf[3] = buf_ld(rCV, usA.jm, sv); tpf[4] = buf_ld(rCV, usA.jc, sv); tpf[5] = buf_ld(rCV, usA.jp, sv);
+        };
+        auto svc_publish = [&](auto pc) __attribute__((always_inline)) {
+            constexpr int P = decltype(pc)::value;
+            lk_d2 ou, ov;
+            ou.x = pyrup_h1v(tpf[0], tpf[1], tpf[2], usA); ou.y = pyrup_h1v(tpf[0], tpf[1], tpf[2], usB);
+            ov.x = pyrup_h1v(tpf[3], tpf[4], tpf[5], usA); ov.y = pyrup_h1v(tpf[3], tpf[4], tpf[5], usB);
+            *reinterpret_cast<lk_d2 *>(&s_c[P][0][2 * m]) = ou;
+            *reinterpret_cast<lk_d2 *>(&s_c[P][1][2 * m]) = ov;
+        };
+        svc_load(2); svc_publish(std::integral_constant<int, 1>{}); svc_load(3);
+        __syncthreads();
+        double pl[2] = {0, 0}, pa[2] = {0, 0}, pb[2] = {0, 0};
+        auto fstepw = [&](auto uc, int t) __attribute__((always_inline)) {
+            constexpr int SP = decltype(uc)::value & 1, WP = SP ^ 1;
+            lk_d2 rw[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int im = 0; im < 2; ++im) rw[e][im] = *reinterpret_cast<const lk_d2 *>(&s_w[WP][e][im][2 * m]);
+            [&]<int... Es>(std::integer_sequence<int, Es...>) __attribute__((always_inline)) {
+                ([&] {
+                    constexpr int E = Es;
+                    double cl[2], ca[2], cb[2];
+#pragma unroll
+                    for (int im = 0; im < 2; ++im) { ca[im] = rw[E][im].x; cb[im] = rw[E][im].y; cl[im] = left_tap(cb[im]); }
+                    const int yy = yy0 + 2 * (t - 2) + E;
+                    const bool row_in = yy >= 0 && yy < H;
+                    double fxa = f2d_x(pl[0], pa[0], cl[0], ca[0]) + f2d_x(pl[1], pa[1], cl[1], ca[1]);
+                    double fya = f2d_y(pl[0], pa[0], cl[0], ca[0]) + f2d_y(pl[1], pa[1], cl[1], ca[1]);
+                    const double fta = f2d_neg(pl[0], pa[0], cl[0], ca[0]) + f2d_pos(pl[1], pa[1], cl[1], ca[1]);
+                    double fxb = f2d_x(pa[0], pb[0], ca[0], cb[0]) + f2d_x(pa[1], pb[1], ca[1], cb[1]);
+                    double fyb = f2d_y(pa[0], pb[0], ca[0], cb[0]) + f2d_y(pa[1], pb[1], ca[1], cb[1]);
+                    const double ftb = f2d_neg(pa[0], pb[0], ca[0], cb[0]) + f2d_pos(pa[1], pb[1], ca[1], cb[1]);
+                    if (!(row_in && all_col_in)) {              // rows / columns outside the image contribute 0 (wave-uniform test)
+                        const bool keep = row_in && col_in;
+                        fxa = keep ? fxa : 0.0; fya = keep ? fya : 0.0;
+                        fxb = keep ? fxb : 0.0; fyb = keep ? fyb : 0.0;
+                    }
+                    auto put = [&](auto fc, double xa_, double xb_) __attribute__((always_inline)) {
+                        lk_d2 o; o.x = xa_; o.y = xb_;
+                        *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][decltype(fc)::value][2 * p_chunk]) = o;
+                    };
+                    put(std::integral_constant<int, 0>{}, fxa * fxa, fxb * fxb);
+                    put(std::integral_constant<int, 1>{}, fya * fya, fyb * fyb);
+                    put(std::integral_constant<int, 2>{}, fxa * fya, fxb * fyb);
+                    put(std::integral_constant<int, 3>{}, fxa * fta, fxb * ftb);
+                    put(std::integral_constant<int, 4>{}, fya * fta, fyb * ftb);
+#pragma unroll
+                    for (int im = 0; im < 2; ++im) { pl[im] = cl[im]; pa[im] = ca[im]; pb[im] = cb[im]; }
+                }(), ...);
+            }(std::make_integer_sequence<int, 2>{});
+            svc_publish(std::integral_constant<int, SP>{});             // the row W-step t + 3 rotates in (W reads it in step t + 1)
+            svc_load(t + 4);
+            SP_BARRIER();
+        };
+        for (int t = 0; t < NS; t += 2) {
+            fstepw(std::integral_constant<int, 0>{}, t);
+            fstepw(std::integral_constant<int, 1>{}, t + 1);
+        }
+      } else {
         const int xa = x0 + 2 * (m - 1);             // even; W even: the pair is all in or all out
         const int pitchb = (int)a.i1.pitch * 8;
         const bool col_in = xa >= 0 && xa < W;
@@ -293,6 +542,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                 (fstep(std::integral_constant<int, Us>{}, st + Us), ...);
             }(std::make_integer_sequence<int, UN>{});
         }
+      }
     } else if (wv < C::NB) {
         // =========================================================================================
         // B waves: one column per lane: window sums -> flow
@@ -300,7 +550,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 #ifdef LK_SPLIT_PRIO_B
         __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_B);
 #endif
-        const int t = threadIdx.x;                   // block column 0 .. TXC-1
+        const int t = ltid;                          // block column 0 .. TXC-1
         const int x = x0 + t;
         const int xc = min(max(x, 0), W - 1);
         const bool is_out = t >= HL && t < HL + XO && x < W;
@@ -430,7 +680,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             SP_STAMP(t2);
             SP_ACC(1, t0, t1); SP_ACC(3, t1, t2);
         };
-        for (int k = 0; k < R + 2; ++k) __syncthreads();       // pipeline fill: no window sums yet
+        for (int k = 0; k < R + 2 + C::LAG + (FW ? 1 : 0); ++k) __syncthreads();   // (FW: W / F prologue,) pipeline fill: no window sums yet
         const int npairs = nrows / 2;
         int p = 0;
         for (; p + TD <= npairs; p += TD) {                     // whole groups
@@ -549,7 +799,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             SP_STAMP(t0);
             SRow rA, rB;
             double SA[K], SB[K];
-            constexpr bool BOTH = WIN <= 15;                 // bigger rings leave no registers for two rows of taps
+            constexpr bool BOTH = WIN <= (FW ? 11 : LK_SPLIT_BOTH_MAX);                 // bigger rings leave no registers for two rows of taps
             sload(SPc{}, E0{}, rA);
             if constexpr (BOTH) sload(SPc{}, E1{}, rB);
 #ifndef LK_SPLIT_NO_WAIT1
@@ -571,7 +821,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
             SP_STAMP(t2);
             SP_ACC(0, t0, t1); SP_ACC(3, t1, t2);
         };
-        __syncthreads();                                     // pipeline step 0: only the front end works
+        for (int k = 0; k < 1 + C::LAG + (FW ? 1 : 0); ++k) __syncthreads();   // pipeline step 0 (FW: W / F prologue, 0..2): only the front end works
         // The van Herk chunks are anchored to ABSOLUTE image rows (chunk position of image row r = r mod WIN), so the
         // order in which a window's rows are added belongs to the output row, not to the strip: results do not depend
         // on the strip height the launcher picks from the batch size (sharded == unsharded bit for bit).
@@ -587,7 +837,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
                 (((unsigned)cnt < (unsigned)nsw ? (sstep(std::integral_constant<int, Ts>{}), 0) : 0, ++cnt), ...);
             }(std::make_integer_sequence<int, 2 * WIN>{});
         }
-        for (int k = nsw + 1; k < NS; ++k) __syncthreads(); // remaining steps: only the back end works / idle tail
+        for (int k = nsw + 1 + C::LAG; k < NS; ++k) __syncthreads(); // remaining steps: only the back end works / idle tail
     }
 #ifdef LK_SPLIT_STAMPS
     if (a.dbg && (threadIdx.x & 63) == 0) {
@@ -605,7 +855,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K>::NT), (SplitCfg<WIN, K>::WPE)) vo
 // inside the image, one thread per pixel, launched after lk_split_kernel on the same stream.  Same expressions as
 // the one-role kernels' clipped branch (lk_products_at, lk_solve, pyrup_at).
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_UP>
+template <bool HAS_UP, bool FW = false>
 __global__ __launch_bounds__(256) void lk_border_kernel(LKArgs a, int win)
 {
     const int R = win / 2, H = a.H, W = a.W, pair = blockIdx.y;
@@ -627,6 +877,21 @@ __global__ __launch_bounds__(256) void lk_border_kernel(LKArgs a, int win)
     if (!(y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2)) return;                          // outermost ring: 0 (+ pyrUp), done by the main kernel
     if (!((y - R < 0) || (y + R > H - 1) || (x - R < 0) || (x + R > W - 1))) return;      // full window: done by the main kernel
     double S[5], u, v;
+    if constexpr (FW) {
+        // fused warp: a.i1 / a.i2 are the UN-warped level images; the four warped taps of both images are made here
+        // (cv::pyrUp of the coarse flow at the tap, float map, remap: warp_kernel's arithmetic)
+        const double *I1 = a.i1.at(pair), *I2 = a.i2.at(pair), *cu = a.cu.at(pair), *cv = a.cv.at(pair);
+        const int ym = r101(y - 1, H), xm = r101(x - 1, W);
+        auto warped = [&](int yy, int xx, double &w1, double &w2) {
+            const float hx = (float)pyrup_at(cu, a.cu.pitch, H >> 1, W >> 1, yy, xx) / 2;
+            const float hy = (float)pyrup_at(cv, a.cv.pitch, H >> 1, W >> 1, yy, xx) / 2;
+            w1 = remap_bilinear(I1, (int)a.i1.pitch, H, W, (float)xx + hx, (float)yy + hy);
+            w2 = remap_bilinear(I2, (int)a.i2.pitch, H, W, (float)xx - hx, (float)yy - hy);
+        };
+        double a00, a01, a10, a11, b00, b01, b10, b11;
+        warped(ym, xm, a00, b00); warped(ym, x, a01, b01); warped(y, xm, a10, b10); warped(y, x, a11, b11);
+        lk_products(a00, a01, a10, a11, b00, b01, b10, b11, S);
+    } else
     lk_products_at(a.i1.at(pair), a.i2.at(pair), a.i1.pitch, H, W, y, x, S);
     for (int f = 0; f < 5; ++f) S[f] = S[f] * (double)(win * win);
     lk_solve(S, u, v);

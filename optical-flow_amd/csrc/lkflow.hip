@@ -43,6 +43,9 @@ struct Level {
 
 }  // namespace
 
+#ifndef LKFLOW_SPLIT_FUSED_DEFAULT
+#define LKFLOW_SPLIT_FUSED_DEFAULT 0                 /* A/B builds: -DLKFLOW_SPLIT_FUSED_DEFAULT=1 */
+#endif
 struct lkflow_ctx {
     int device = 0;
     int n_cu = 256;
@@ -50,6 +53,7 @@ struct lkflow_ctx {
     std::string last_error;
     // options
     int impl = 0;
+    int fuse_warp = LKFLOW_SPLIT_FUSED_DEFAULT;   // LKFLOW_OPT_FUSE_WARP
     int tile_rows = 0;
     int profile = 0;
     struct Rec { hipEvent_t a, b; int slot; };
@@ -336,12 +340,70 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
     return LKFLOW_OK;
 }
 
+// Warp fused into the wave-specialised kernel (lk_split.h, W role): a.i1 / a.i2 are the UN-warped level images,
+// the warped planes never reach memory.  -1: shape not taken (the caller runs warp + LK).
+template <int WIN, int K>
+int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
+{
+    using C = lk::SplitCfg<WIN, K, true>;
+    if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return -1;
+    // the W role addresses a whole image plane with 32-bit byte offsets and one pitch for both images
+    if (a.i1.pitch != a.i2.pitch || (long long)a.H * a.i1.pitch * 8 > 0x7fffffffLL) return -1;
+    const int gx = (a.W + C::XO - 1) / C::XO;
+    int th = ctx->tile_rows;
+    if (th <= 0) {
+        const int bpc = blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, true, true>, C::NT);
+        th = pick_tile_rows(a.H, C::R + 2, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
+    }
+    th = (th + 1) & ~1;
+    {
+        const long long pmax = std::max(a.u.pitch, a.v.pitch);
+        const long long cap = (0x7fffffffLL / (pmax * 8) - 2 * C::R - 8) & ~1LL;
+        if (cap < 2) return LKFLOW_E_ARG;
+        if (th > cap) th = (int)cap;
+    }
+    a.th = th;
+    a.gx = gx; a.gy = (a.H + th - 1) / th;
+    if ((long long)a.gx * a.gy * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
+    hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true, true>), dim3((unsigned)(a.gx * a.gy * pairs)), dim3(C::NT), 0, s, a);
+    {   // the frame of clipped-window pixels, overwritten in stream order (its warped taps are made on the fly)
+        const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
+        const long long n = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
+        hipLaunchKernelGGL((lk::lk_border_kernel<true, true>), dim3((unsigned)((n + 255) / 256), pairs), dim3(256), 0, s, a, WIN);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
+#define LKFLOW_SPLIT_FUSED_MAX_WIN 15                // bigger rings do not fit the 96 VGPRs of a 10-wave block pair
+bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H);
+
+int launch_splitw(lkflow_ctx *ctx, const lk::LKArgs &a, int pairs, int win, hipStream_t s)
+{
+    switch (win) {
+#define SP_CASE(WN) case WN: return launch_splitw_win<WN, 2>(ctx, a, pairs, s);
+#ifdef LKFLOW_FAST_BUILD
+        SP_CASE(15)
+#else
+        SP_CASE(5) SP_CASE(7) SP_CASE(9) SP_CASE(11) SP_CASE(13) SP_CASE(15)
+#endif
+#undef SP_CASE
+        default: return -1;
+    }
+}
+
 // shapes the wave-specialised kernel takes (the rest -- odd or tiny levels -- runs the one-role kernel)
 bool split_applies(int win, int W, int H)
 {
     static const int split = getenv("LKFLOW_SPLIT") ? atoi(getenv("LKFLOW_SPLIT")) : 1;   // debug knob (A/B): 0 = one-role kernel
     const int R = win / 2;
     return split && win >= 5 && win <= LKFLOW_MAX_WIN && !(W & 1) && !(H & 1) && W >= 2 && H > R + LK_SPLIT_PF + 1;
+}
+
+bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H)
+{
+    static const int env = getenv("LKFLOW_SPLIT_FUSED") ? atoi(getenv("LKFLOW_SPLIT_FUSED")) : -1;   // debug knob (A/B): overrides the option
+    return (env >= 0 ? env : ctx->fuse_warp) && ctx->impl == 0 && win <= LKFLOW_SPLIT_FUSED_MAX_WIN && split_applies(win, W, H);
 }
 
 // -1: this window has no wave-specialised instantiation
@@ -601,6 +663,10 @@ int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value)
             if (value < 0 || value > 1) return LKFLOW_E_ARG;
             ctx->impl = value;
             return LKFLOW_OK;
+        case LKFLOW_OPT_FUSE_WARP:
+            if (value < 0 || value > 1) return LKFLOW_E_ARG;
+            ctx->fuse_warp = value;
+            return LKFLOW_OK;
         case LKFLOW_OPT_TILE_ROWS:
             if (value < 0 || value > 4096) return LKFLOW_E_ARG;
             ctx->tile_rows = value;
@@ -764,6 +830,16 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
             ProfScope ps(ctx, LKFLOW_STAGE_LK, l, s);
             if ((rc = launch_w3x2f(ctx, a, P, s))) return rc;
             continue;
+        }
+        if (has_up && fused_split_applies(ctx, win, lv[l].W, lv[l].H) && !((flags & LKFLOW_MUTATE_INPUTS) && l == 0)) {
+            // windows 5..15: warp and LK in one kernel (lk_split.h, W role), the warped images never reach memory
+            lk::LKArgs f = a;
+            f.i1 = pyr(l, 0); f.i2 = pyr(l, 1);
+            f.cu = as_c(flow_w(l + 1, 0)); f.cv = as_c(flow_w(l + 1, 1));
+            ProfScope ps(ctx, LKFLOW_STAGE_LK, l, s);
+            rc = launch_splitw(ctx, f, P, win, s);
+            if (rc == LKFLOW_OK) continue;
+            if (rc != -1) return rc;                             // -1: shape not taken, warp + LK below
         }
         if (has_up) {
             CPlanes cu = as_c(flow_w(l + 1, 0)), cv = as_c(flow_w(l + 1, 1));

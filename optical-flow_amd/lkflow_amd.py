@@ -34,6 +34,7 @@ LKFLOW_OPT_IMPL = 1
 LKFLOW_OPT_TILE_ROWS = 2
 LKFLOW_OPT_PROFILE = 3
 LKFLOW_OPT_PIN_HOST = 4
+LKFLOW_OPT_FUSE_WARP = 5
 LKFLOW_STAGE_PYRDOWN, LKFLOW_STAGE_WARP, LKFLOW_STAGE_LK = 0, 1, 2
 LKFLOW_N_STAGES, LKFLOW_MAX_LEVELS = 3, 32
 
