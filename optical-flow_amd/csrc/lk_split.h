@@ -35,6 +35,11 @@
 // marches in lock-step: every wave reads LDS, computes and writes at the same time).  1-D grid, XCD-aware tile
 // order (column blocks of a strip and vertically adjacent strips share halo lines through one L2).
 //
+// FW = true (opt-in, LKFLOW_OPT_FUSE_WARP): two more "W" waves per block run the warp of the level (a9-a12: cv::pyrUp of
+// the coarse flow, float map, fixed-point remap of both UN-warped images) and hand the rows to F through LDS, so the warped
+// planes never reach memory; F then serves W the filtered coarse rows.  Bit-identical to warp_kernel + this kernel, but
+// slower on MI355X: a 10-wave block does not share a CU with a second one, so it is not the default.
+//
 // Only additions in the window sums (flat regions give exactly 0 like the reference); same products, solve and pyrUp
 // expressions as lk_march3.h.  Host-checked: W and H even, H > R + PF + 1, even strip height (a step's row pair is an
 // even and an odd output row); other shapes take lk_march3.h.  -DLK_SPLIT_STAMPS / -DLK_SPLIT_ABL_* are diagnostic
