@@ -219,8 +219,20 @@ def preprocess_rate(ctx, torch, device, frames=33, side=1080, steps=20):
         ctx.preprocess_bgr(bgr)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # the step in front of it (ParallelVideoPyr.cpp:778): resize(frame, .., Size(1080, 1080), 0, 0, INTER_CUBIC) of 720p frames
+    cam = torch.randint(0, 256, (frames, 720, 1280, 3), dtype=torch.uint8, generator=g).to(f"cuda:{device}")
+    for _ in range(3):
+        ctx.resize_cubic(cam, side, side)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.resize_cubic(cam, side, side)
+    torch.cuda.synchronize()
+    dr = (time.perf_counter() - t0) / steps
     return {"frames": frames, "shape": [side, side, 3], "ms_per_batch": round(dt * 1e3, 4),
             "frames_per_s": round(frames / dt, 1), "algorithmic_GBps": round(14.0 * frames * side * side / dt / 1e9, 1),
+            "resize_cubic": {"from": [720, 1280, 3], "ms_per_batch": round(dr * 1e3, 4), "frames_per_s": round(frames / dr, 1),
+                             "algorithmic_GBps": round(3.0 * frames * (720 * 1280 + side * side) / dr / 1e9, 1)},
             "note": "rank 0 only, extra measurement after the timed region; uint8 BGR in -> CV_64F edge images out"}
 
 

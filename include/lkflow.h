@@ -185,13 +185,24 @@ int lkflow_u8_to_f64_dev(lkflow_ctx *ctx, const unsigned char *src, double *dst,
                          void *stream);
 
 /*
+ * First step of the video loop's frame pre-processing (ParallelVideoPyr.cpp:778): resize(frame, current_frame,
+ * Size(dst_cols, dst_rows), 0, 0, INTER_CUBIC) on 8UC3 (BGR, interleaved) frames; OpenCV 2.4's 8-bit path (11-bit
+ * fixed-point cubic weights, A = -0.75; clamped borders; x86 SSE2 build: the vertical pass runs in float for all but
+ * the last (dst_cols * 3) mod 8 bytes of a row).  The reference calls it with Size(1080, 1080).
+ * src: n_frames frames of src_rows x src_cols x 3 bytes (row step src_step_bytes); dst: dst_rows x dst_cols x 3 each.
+ */
+int lkflow_resize_cubic_bgr8_dev(lkflow_ctx *ctx, const unsigned char *src, size_t src_plane_stride_bytes,
+                                 int n_frames, int src_rows, int src_cols, size_t src_step_bytes,
+                                 unsigned char *dst, size_t dst_plane_stride_bytes, int dst_rows, int dst_cols,
+                                 size_t dst_step_bytes, void *stream);
+
+/*
  * Frame pre-processing of the video loop (ParallelVideoPyr.cpp:786-787): GaussianBlur(frame, frame,
  * Size(ksize,ksize), sigma, sigma) on the 8UC3 (BGR, interleaved) frame followed by
  * cvtColor(.., CV_BGR2GRAY); OpenCV 2.4's 8-bit fixed-point arithmetic (x86 SSE2 build: column pass rounds
  * half to even).  The reference calls it with ksize 9, sigma 1.5.  ksize odd, <= 15; sigma > 0.
  * bgr: n_frames frames of rows x cols x 3 bytes (row step src_step_bytes); gray: rows x cols bytes each.
- * (The resize to 1080 x 1080 that precedes it, :778, is not part of this library: pass frames of the
- * size the flow should run at.)
+ * (The resize to 1080 x 1080 that precedes it, :778: lkflow_resize_cubic_bgr8_dev.)
  */
 int lkflow_blur_gray_bgr8_dev(lkflow_ctx *ctx, const unsigned char *bgr, size_t src_plane_stride_bytes,
                               int n_frames, int rows, int cols, size_t src_step_bytes, int ksize, double sigma,

@@ -562,6 +562,83 @@ __global__ __launch_bounds__(256) void blur_gray_kernel(BlurGrayArgs a)
 // f2: diff = cur - rate * prev on 8UC1 frames (ParallelVideoPyr.cpp:800) = cv::addWeighted(cur, 1,
 // prev, -rate, 0): FLOAT arithmetic, every product and sum rounded, round-half-even, saturate.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// f2, ParallelVideoPyr.cpp:778: resize(frame, .., Size(dcols, drows), 0, 0, INTER_CUBIC) on 8UC3 frames, OpenCV 2.4's
+// 8-bit path (imgwarp.cpp resizeGeneric_<HResizeCubic<uchar,int,short>, VResizeCubic<.., VResizeCubicVec_32s8u>>):
+// 11-bit fixed-point weights from float cubic coefficients (A = -0.75), horizontal pass 8U -> 32S with clamped
+// indices, vertical pass in FLOAT for the row elements the SSE2 vector op covers (all but the last width*3 mod 8)
+// and in 32-bit integers (+ 2^21, >> 22) for the rest.  One thread per destination pixel; the weights of its column
+// and row are recomputed per thread (the same IEEE operations in the same order as the host-side tables of OpenCV).
+// ------------------------------------------------------------------------------------------------
+struct ResizeArgs {
+    const unsigned char *src; long long src_plane, src_pitch;
+    unsigned char *dst; long long dst_plane, dst_pitch;
+    int srows, scols, drows, dcols;
+    double scale_x, scale_y;        // 1 / ((double)dsize / ssize)
+};
+
+__device__ __forceinline__ int cubic_weights_q11(int d, double scale, short w[4])
+{
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    const int s = (int)floorf(f);
+    f = __fsub_rn(f, (float)s);
+    const float A = -0.75f, x = f, x1 = __fadd_rn(x, 1.0f), xm = __fsub_rn(1.0f, x);
+    float c[4], t;
+    t = __fmul_rn(A, x1); t = __fsub_rn(t, 5.0f * A); t = __fmul_rn(t, x1); t = __fadd_rn(t, 8.0f * A); t = __fmul_rn(t, x1); c[0] = __fsub_rn(t, 4.0f * A);
+    t = __fmul_rn(A + 2.0f, x); t = __fsub_rn(t, A + 3.0f); t = __fmul_rn(t, x); t = __fmul_rn(t, x); c[1] = __fadd_rn(t, 1.0f);
+    t = __fmul_rn(A + 2.0f, xm); t = __fsub_rn(t, A + 3.0f); t = __fmul_rn(t, xm); t = __fmul_rn(t, xm); c[2] = __fadd_rn(t, 1.0f);
+    t = __fsub_rn(1.0f, c[0]); t = __fsub_rn(t, c[1]); c[3] = __fsub_rn(t, c[2]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int v = __float2int_rn(__fmul_rn(c[k], 2048.0f));      // saturate_cast<short>(w * INTER_RESIZE_COEF_SCALE)
+        w[k] = (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void resize_cubic_kernel(ResizeArgs a)
+{
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y, n = blockIdx.z;
+    if (dx >= a.dcols) return;
+    short al[4], be[4];
+    const int xo = cubic_weights_q11(dx, a.scale_x, al), yo = cubic_weights_q11(dy, a.scale_y, be);
+    int sx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sx[j] = min(max(xo - 1 + j, 0), a.scols - 1) * 3;
+    const unsigned char *S = a.src + (long long)n * a.src_plane;
+    int h[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned char *row = S + (long long)min(max(yo - 1 + k, 0), a.srows - 1) * a.src_pitch;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v += (int)row[sx[j] + c] * (int)al[j];
+            h[k][c] = v;
+        }
+    }
+    const int vec_end = (a.dcols * 3) & ~7;                          // row elements the SSE2 vector op covers
+    const float scale = 1.0f / (2048.0f * 2048.0f);
+    const float b0 = __fmul_rn((float)be[0], scale), b1 = __fmul_rn((float)be[1], scale), b2 = __fmul_rn((float)be[2], scale),
+                b3 = __fmul_rn((float)be[3], scale);
+    unsigned char *o = a.dst + (long long)n * a.dst_plane + (long long)dy * a.dst_pitch + dx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int v;
+        if (dx * 3 + c < vec_end) {
+            float s = __fmul_rn((float)h[0][c], b0);
+            s = __fadd_rn(s, __fmul_rn((float)h[1][c], b1));
+            s = __fadd_rn(s, __fmul_rn((float)h[2][c], b2));
+            s = __fadd_rn(s, __fmul_rn((float)h[3][c], b3));
+            v = __float2int_rn(s);
+        } else {
+            v = (h[0][c] * be[0] + h[1][c] * be[1] + h[2][c] * be[2] + h[3][c] * be[3] + (1 << 21)) >> 22;
+        }
+        o[c] = (unsigned char)min(max(v, 0), 255);
+    }
+}
+
 struct FrameDiffArgs {
     const unsigned char *cur, *prev;
     long long src_plane, src_pitch;

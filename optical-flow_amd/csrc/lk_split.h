@@ -138,7 +138,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
 {
     using C = SplitCfg<WIN, K, FW>;
     static_assert(!FW || HAS_UP, "the fused warp needs a coarser level");
-    constexpr int R = C::R, TXC = C::TXC, XO = C::XO, KH = C::KH, PADJ = C::PADJ, PF = C::PF, UN = C::UN, HL = C::HL;
+    constexpr int R = C::R, XO = C::XO, KH = C::KH, PADJ = C::PADJ, PF = C::PF, UN = C::UN, HL = C::HL;
     __shared__ __attribute__((aligned(16))) double s_prod[2][2][5][C::PROD_D];   // [step parity][row of the step][field]: (a, b) products of every column pair
     __shared__ double s_q[C::QSUM ? 2 : 1][C::QSUM ? 2 : 1][C::QSUM ? 5 : 1][C::QSUM ? C::NJP : 1];   // the pair sums a + b (index = chunk), if F publishes them
     __shared__ __attribute__((aligned(16))) double s_sums[2][2][5][C::SUMS_D];
@@ -209,6 +209,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     if (!FW && wv > C::NB + 5) {                     // diagnostic idle waves (LK_SPLIT_IDLE_WAVES)
         for (int k = 0; k < NS; ++k) __syncthreads();
     } else if (FW && wv > C::NB + 5) {
+      if constexpr (FW) {                            // (not even compiled for the unfused kernel)
         // =========================================================================================
         // W waves (fused warp, a9-a12): one column per lane -> the warped rows of both images, through LDS to F
         // =========================================================================================
@@ -338,6 +339,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             wstep(std::integral_constant<int, 0>{}, t);
             wstep(std::integral_constant<int, 1>{}, t + 1);
         }
+      }
     } else if (wv >= C::NB + 5) {
         // =========================================================================================
         // F waves: two adjacent columns per lane -> products
@@ -837,7 +839,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         int t0s = (kc0 & 1) ? (kc0 + WIN) / 2 : kc0 / 2;     // 2 t0s = kc0 (mod WIN), 0 <= t0s < WIN
         if (t0s & 1) t0s += WIN;                             // WIN is odd: the other solution is even
         int cnt = -t0s;                                      // work step number of body position 0 in the first pass
-        for (; cnt < nsw; ) {
+        while (cnt < nsw) {
             [&]<int... Ts>(std::integer_sequence<int, Ts...>) __attribute__((always_inline)) {
                 (((unsigned)cnt < (unsigned)nsw ? (sstep(std::integral_constant<int, Ts>{}), 0) : 0, ++cnt), ...);
             }(std::make_integer_sequence<int, 2 * WIN>{});

@@ -1158,6 +1158,27 @@ int lkflow_blur_gray_bgr8_dev(lkflow_ctx *ctx, const unsigned char *bgr, size_t 
     return LKFLOW_OK;
 }
 
+int lkflow_resize_cubic_bgr8_dev(lkflow_ctx *ctx, const unsigned char *src, size_t src_ps, int n_frames, int src_rows,
+                                 int src_cols, size_t src_step_bytes, unsigned char *dst, size_t dst_ps, int dst_rows,
+                                 int dst_cols, size_t dst_step_bytes, void *stream)
+{
+    if (!ctx || !src || !dst || n_frames < 1 || src_rows < 1 || src_cols < 1 || dst_rows < 1 || dst_cols < 1) return LKFLOW_E_ARG;
+    if (src_step_bytes < (size_t)src_cols * 3 || dst_step_bytes < (size_t)dst_cols * 3) return LKFLOW_E_ARG;
+    if (n_frames > 65535 || dst_rows > 65535 || src_cols > (1 << 24) || src_rows > (1 << 24) || dst_cols > (1 << 24)) return LKFLOW_E_ARG;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    lk::ResizeArgs a{};
+    a.src = src; a.src_plane = (long long)src_ps; a.src_pitch = (long long)src_step_bytes;
+    a.dst = dst; a.dst_plane = (long long)dst_ps; a.dst_pitch = (long long)dst_step_bytes;
+    a.srows = src_rows; a.scols = src_cols; a.drows = dst_rows; a.dcols = dst_cols;
+    a.scale_x = 1.0 / ((double)dst_cols / src_cols);         // cv::resize: inv_scale = (double)dsize / ssize; scale = 1 / inv_scale
+    a.scale_y = 1.0 / ((double)dst_rows / src_rows);
+    hipLaunchKernelGGL(lk::resize_cubic_kernel, dim3((dst_cols + 255) / 256, dst_rows, n_frames), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
 int lkflow_frame_diff_u8_dev(lkflow_ctx *ctx, const unsigned char *cur, const unsigned char *prev, size_t src_ps,
                              int n_planes, int rows, int cols, size_t src_step_bytes, double rate,
                              unsigned char *diff, size_t dst_ps, size_t dst_step_bytes, void *stream)

@@ -73,6 +73,7 @@ SIGNATURES = {
                                  _sz, _sz, _vp]),
     "lkflow_u8_to_f64_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "lkflow_blur_gray_bgr8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _i, _d, _vp, _sz, _sz, _vp]),
+    "lkflow_resize_cubic_bgr8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _vp, _sz, _i, _i, _sz, _vp]),
     "lkflow_frame_diff_u8_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _vp, _sz, _sz, _vp]),
     "lkflow_edge_map_u8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _i, _vp, _sz, _sz, _vp]),
     "lkflow_diff_edge_map_u8_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _i, _vp, _sz, _sz, _vp]),
@@ -409,6 +410,21 @@ class Context:
         self._chk(lib().lkflow_u8_to_f64_dev(self._h, src.data_ptr(), dst.data_ptr(), src.numel(),
                                              _stream_ptr(stream)))
         return dst
+
+    def resize_cubic(self, bgr_u8, rows=1080, cols=1080, stream=None):
+        """[N,Hs,Ws,3] uint8 BGR frames -> [N,rows,cols,3] uint8: resize(.., Size(cols, rows), 0, 0, INTER_CUBIC)
+        (ParallelVideoPyr.cpp:778; OpenCV 2.4 8-bit fixed-point arithmetic)."""
+        torch = _torch()
+        assert bgr_u8.is_cuda and bgr_u8.dtype == torch.uint8
+        if bgr_u8.dim() == 3:
+            bgr_u8 = bgr_u8.unsqueeze(0)
+        assert bgr_u8.shape[-1] == 3 and bgr_u8.stride(-1) == 1 and bgr_u8.stride(2) == 3
+        N, H, W, _ = bgr_u8.shape
+        out = torch.empty((N, rows, cols, 3), dtype=torch.uint8, device=bgr_u8.device)
+        self._chk(lib().lkflow_resize_cubic_bgr8_dev(self._h, bgr_u8.data_ptr(), bgr_u8.stride(0), N, H, W,
+                                                     bgr_u8.stride(1), out.data_ptr(), out.stride(0), int(rows),
+                                                     int(cols), out.stride(1), _stream_ptr(stream)))
+        return out
 
     def blur_gray(self, bgr_u8, ksize=9, sigma=1.5, stream=None):
         """[N,H,W,3] uint8 BGR frames -> [N,H,W] uint8: GaussianBlur(ksize x ksize, sigma) on the colour frame,

@@ -524,3 +524,85 @@ void lko_frame_diff_u8(const unsigned char *cur, const unsigned char *prev, long
         diff[i] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
     }
 }
+
+/*
+ * ParallelVideoPyr.cpp:778 -- resize(frame, current_frame, Size(1080, 1080), 0, 0, INTER_CUBIC) on the 8UC3 frame.
+ * PARITY UNPINNED: the reference holds no fixture for its pre-processing chain and OpenCV is absent, so this
+ * restates OpenCV 2.4's published algorithm (imgwarp.cpp: cv::resize -> resizeGeneric_<HResizeCubic<uchar,int,short>,
+ * VResizeCubic<uchar,int,short,FixedPtCast<int,uchar,22>,VResizeCubicVec_32s8u>>):
+ *   scale = 1 / ((double)dsize / ssize); per destination index d: f = (float)((d + 0.5) * scale - 0.5), s = floor(f),
+ *     f -= s; the four cubic weights (A = -0.75, float arithmetic, interpolateCubic) are stored as
+ *     saturate_cast<short>(w * 2048) (cvRound: half to even);
+ *   horizontal pass 8U -> 32S over the taps s-1 .. s+2 of each channel, indices outside the row clamped to its ends;
+ *   vertical pass over the rows s-1 .. s+2 (clamped): the x86 SSE2 vector op (what the reference's x86-64 binary runs)
+ *     takes the row elements 8 at a time, in FLOAT -- ((S0*b0 + S1*b1) + S2*b2) + S3*b3 with b = beta / 2^22, every
+ *     product and sum rounded to float, cvtps2dq (half to even), saturated to 0..255; the last (width*3) mod 8 elements of
+ *     a row take the scalar path (S0*b0 + S1*b1 + S2*b2 + S3*b3 + 2^21) >> 22 in 32-bit integers.
+ */
+static void cubic_tab(int ssize, int dsize, int *ofs, short *coef)
+{
+    const double scale = 1.0 / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; ++d) {
+        volatile float f = (float)((d + 0.5) * scale - 0.5);
+        const int s = (int)floorf(f);
+        f = f - (float)s;
+        const float A = -0.75f, x = f;
+        volatile float c[4], t;                              /* volatile: every step rounded to float, nothing fused */
+        t = A * (x + 1.0f); t = t - 5.0f * A; t = t * (x + 1.0f); t = t + 8.0f * A; t = t * (x + 1.0f); c[0] = t - 4.0f * A;
+        t = (A + 2.0f) * x; t = t - (A + 3.0f); t = t * x; t = t * x; c[1] = t + 1.0f;
+        t = (A + 2.0f) * (1.0f - x); t = t - (A + 3.0f); t = t * (1.0f - x); t = t * (1.0f - x); c[2] = t + 1.0f;
+        t = 1.0f - c[0]; t = t - c[1]; c[3] = t - c[2];
+        ofs[d] = s;
+        for (int k = 0; k < 4; ++k) {
+            long v = lrintf(c[k] * 2048.0f);                 /* INTER_RESIZE_COEF_SCALE = 1 << 11 */
+            coef[4 * d + k] = (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+        }
+    }
+}
+
+void lko_resize_cubic_tables(int ssize, int dsize, int *ofs, short *coef) { cubic_tab(ssize, dsize, ofs, coef); }
+
+void lko_resize_cubic_bgr8(const unsigned char *src, int srows, int scols, int drows, int dcols, unsigned char *dst)
+{
+    int *xofs = (int *)malloc((size_t)dcols * sizeof(int)), *yofs = (int *)malloc((size_t)drows * sizeof(int));
+    short *alpha = (short *)malloc((size_t)dcols * 4 * sizeof(short)), *beta = (short *)malloc((size_t)drows * 4 * sizeof(short));
+    int *rows4 = (int *)malloc((size_t)4 * dcols * 3 * sizeof(int));
+    cubic_tab(scols, dcols, xofs, alpha);
+    cubic_tab(srows, drows, yofs, beta);
+    const int width = dcols * 3, vec_end = width & ~7;
+    const float scale = 1.0f / (2048.0f * 2048.0f);
+    for (int dy = 0; dy < drows; ++dy) {
+        for (int k = 0; k < 4; ++k) {                        /* horizontal pass of the four source rows */
+            int sy = yofs[dy] - 1 + k;
+            sy = sy < 0 ? 0 : (sy > srows - 1 ? srows - 1 : sy);
+            const unsigned char *S = src + (size_t)sy * scols * 3;
+            int *D = rows4 + (size_t)k * width;
+            for (int dx = 0; dx < dcols; ++dx)
+                for (int c = 0; c < 3; ++c) {
+                    int v = 0;
+                    for (int j = 0; j < 4; ++j) {
+                        int sx = xofs[dx] - 1 + j;
+                        sx = sx < 0 ? 0 : (sx > scols - 1 ? scols - 1 : sx);
+                        v += S[sx * 3 + c] * alpha[4 * dx + j];
+                    }
+                    D[dx * 3 + c] = v;
+                }
+        }
+        const short *b = beta + 4 * dy;
+        const int *S0 = rows4, *S1 = rows4 + width, *S2 = rows4 + 2 * width, *S3 = rows4 + 3 * width;
+        const float b0 = b[0] * scale, b1 = b[1] * scale, b2 = b[2] * scale, b3 = b[3] * scale;
+        unsigned char *o = dst + (size_t)dy * width;
+        for (int x = 0; x < width; ++x) {
+            long v;
+            if (x < vec_end) {
+                volatile float s = (float)S0[x] * b0, f = (float)S1[x] * b1;
+                s = s + f; f = (float)S2[x] * b2; s = s + f; f = (float)S3[x] * b3; s = s + f;
+                v = lrintf(s);
+            } else {
+                v = (S0[x] * b[0] + S1[x] * b[1] + S2[x] * b[2] + S3[x] * b[3] + (1 << 21)) >> 22;
+            }
+            o[x] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+    free(rows4); free(beta); free(alpha); free(yofs); free(xofs);
+}

@@ -74,6 +74,11 @@ void lko_blur_gray_bgr8(const unsigned char *bgr, int rows, int cols, int ksize,
 void lko_frame_diff_u8(const unsigned char *cur, const unsigned char *prev, long n, double rate,
                        unsigned char *diff);
 
+/* ParallelVideoPyr.cpp:778 resize(frame, .., Size(dcols, drows), 0, 0, INTER_CUBIC) on 8UC3 (OpenCV 2.4 fixed-point
+ * tables, SSE2 float vertical pass). PARITY UNPINNED.  _tables: source offset and the four 11-bit weights per index. */
+void lko_resize_cubic_tables(int ssize, int dsize, int *ofs, short *coef);
+void lko_resize_cubic_bgr8(const unsigned char *src, int srows, int scols, int drows, int dcols, unsigned char *dst);
+
 #ifdef __cplusplus
 }
 #endif

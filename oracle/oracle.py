@@ -78,6 +78,10 @@ def lib():
         L.lko_blur_gray_bgr8.restype = None
         L.lko_frame_diff_u8.argtypes = [_bp, _bp, ctypes.c_long, ctypes.c_double, _bp]
         L.lko_frame_diff_u8.restype = None
+        L.lko_resize_cubic_tables.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_short)]
+        L.lko_resize_cubic_tables.restype = None
+        L.lko_resize_cubic_bgr8.argtypes = [_bp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _bp]
+        L.lko_resize_cubic_bgr8.restype = None
         _LIB = L
     return _LIB
 
@@ -191,6 +195,25 @@ def blur_gray_bgr8(bgr, ksize=9, sigma=1.5):
     _bp = ctypes.POINTER(ctypes.c_ubyte)
     lib().lko_blur_gray_bgr8(bgr.ctypes.data_as(_bp), bgr.shape[0], bgr.shape[1], ksize, float(sigma),
                              out.ctypes.data_as(_bp))
+    return out
+
+
+def resize_cubic_tables(ssize, dsize):
+    ofs = np.empty(dsize, dtype=np.int32)
+    coef = np.empty((dsize, 4), dtype=np.int16)
+    lib().lko_resize_cubic_tables(int(ssize), int(dsize), ofs.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                  coef.ctypes.data_as(ctypes.POINTER(ctypes.c_short)))
+    return ofs, coef
+
+
+def resize_cubic_bgr8(bgr, drows, dcols):
+    """ParallelVideoPyr.cpp:778 resize(.., Size(dcols, drows), 0, 0, INTER_CUBIC) on an 8UC3 frame (parity unpinned)."""
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    assert bgr.ndim == 3 and bgr.shape[2] == 3
+    out = np.empty((drows, dcols, 3), dtype=np.uint8)
+    _bp = ctypes.POINTER(ctypes.c_ubyte)
+    lib().lko_resize_cubic_bgr8(bgr.ctypes.data_as(_bp), bgr.shape[0], bgr.shape[1], int(drows), int(dcols),
+                                out.ctypes.data_as(_bp))
     return out
 
 

@@ -175,3 +175,19 @@ def test_fused_warp_option_is_bit_identical(lkflow, torch, rows, cols, levels, w
         torch.cuda.synchronize()
     assert float(U0.abs().max()) > 0.1                     # the pair really moves
     assert torch.equal(U0, U1) and torch.equal(V0, V1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src_shape,dst_shape", [((480, 640), (1080, 1080)), ((720, 1280), (1080, 1080)), ((1080, 1080), (1080, 1080)),
+                                                  ((30, 40), (37, 101)), ((5, 7), (40, 33)), ((1, 1), (9, 9)), ((2, 3), (3, 2)),
+                                                  ((1080, 1920), (540, 960))])
+def test_resize_cubic_bit_exact(gpu_ctx, oracle, torch, src_shape, dst_shape):
+    """f2 / ParallelVideoPyr.cpp:778 (parity unpinned: no fixture, OpenCV absent): the HIP kernel against the oracle's
+    restatement of OpenCV 2.4's 8-bit cubic resize, byte for byte, incl. row tails that take the integer path."""
+    rng = np.random.default_rng(src_shape[1] * 7 + dst_shape[0])
+    src = rng.integers(0, 256, size=(2,) + src_shape + (3,), dtype=np.uint8)
+    got = gpu_ctx.resize_cubic(torch.from_numpy(src).cuda(), *dst_shape).cpu().numpy()
+    for k in range(2):
+        assert np.array_equal(got[k], oracle.resize_cubic_bgr8(src[k], *dst_shape))
+    with pytest.raises(Exception):
+        gpu_ctx.resize_cubic(torch.from_numpy(src).cuda(), 0, 5)

@@ -206,3 +206,72 @@ def test_frame_diff_oracle_matches_float32_numpy(oracle):
     got = oracle.frame_diff_u8(a, b, 0.3)
     assert np.array_equal(got, want)
     assert got[255, 0] == 0 and got[0, 255] == 255               # saturates at 0; cur alone passes through
+
+
+# ---- f2: resize(.., Size(1080, 1080), 0, 0, INTER_CUBIC) on the 8UC3 frame (ParallelVideoPyr.cpp:778) -- parity unpinned ----
+def _np_cubic_tab(ssize, dsize):
+    """Independent NumPy form of OpenCV 2.4's cubic tables (imgwarp.cpp cv::resize + interpolateCubic), float32 per operation."""
+    f32 = np.float32
+    scale = 1.0 / (float(dsize) / ssize)
+    f = ((np.arange(dsize, dtype=np.float64) + 0.5) * scale - 0.5).astype(f32)
+    s = np.floor(f).astype(np.int32)
+    x = f - s.astype(f32)
+    A = f32(-0.75)
+    x1, xm = x + f32(1), f32(1) - x
+    c0 = ((A * x1 - f32(5) * A) * x1 + f32(8) * A) * x1 - f32(4) * A
+    c1 = ((A + f32(2)) * x - (A + f32(3))) * x * x + f32(1)
+    c2 = ((A + f32(2)) * xm - (A + f32(3))) * xm * xm + f32(1)
+    c3 = f32(1) - c0 - c1 - c2
+    c = np.stack([c0, c1, c2, c3], axis=1)
+    assert c.dtype == np.float32
+    return s, np.clip(np.rint(c * f32(2048)), -32768, 32767).astype(np.int32)
+
+
+def _np_resize_cubic(src, drows, dcols):
+    srows, scols, _ = src.shape
+    xo, al = _np_cubic_tab(scols, dcols)
+    yo, be = _np_cubic_tab(srows, drows)
+    xi = np.clip(xo[:, None] + np.arange(-1, 3)[None, :], 0, scols - 1)            # [dcols, 4]
+    H = (src.astype(np.int32)[:, xi, :] * al[None, :, :, None]).sum(axis=2)         # [srows, dcols, 3] int32
+    H = H.reshape(srows, dcols * 3)
+    yi = np.clip(yo[:, None] + np.arange(-1, 3)[None, :], 0, srows - 1)            # [drows, 4]
+    S = H[yi]                                                                       # [drows, 4, width]
+    f32 = np.float32
+    b = be.astype(f32) * (f32(1) / (f32(2048) * f32(2048)))
+    Sf = S.astype(f32)
+    acc = Sf[:, 0] * b[:, 0:1]
+    for k in (1, 2, 3):
+        acc = acc + Sf[:, k] * b[:, k:k + 1]
+    vf = np.rint(acc).astype(np.int64)
+    vi = ((S.astype(np.int64) * be[:, :, None]).sum(axis=1) + (1 << 21)) >> 22
+    width = dcols * 3
+    v = np.where(np.arange(width)[None, :] < (width & ~7), vf, vi)
+    return np.clip(v, 0, 255).astype(np.uint8).reshape(drows, dcols, 3)
+
+
+@pytest.mark.parametrize("src_shape,dst_shape", [((48, 64), (108, 108)), ((72, 128), (54, 54)), ((30, 40), (37, 101)),
+                                                  ((5, 7), (40, 33)), ((1, 1), (9, 9)), ((2, 3), (3, 2))])
+def test_resize_cubic_matches_independent_numpy_form(oracle, src_shape, dst_shape):
+    rng = np.random.default_rng(src_shape[0] * 1000 + dst_shape[1])
+    src = rng.integers(0, 256, size=src_shape + (3,), dtype=np.uint8)
+    got = oracle.resize_cubic_bgr8(src, *dst_shape)
+    assert np.array_equal(got, _np_resize_cubic(src, *dst_shape))
+
+
+def test_resize_cubic_known_answers(oracle):
+    """What any reading of the algorithm must give: a same-size resize is the identity (weights 0, 2048, 0, 0), a flat
+    image stays flat, the 1/2-pixel phase of a 2x up-sampling has the textbook weights (-3/32, 19/32, 19/32, -3/32) * ... in
+    Q11 = the cubic kernel with A = -0.75 at x = 0.25 / 0.75."""
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, size=(31, 45, 3), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_cubic_bgr8(src, 31, 45), src)
+    flat = np.full((20, 30, 3), 200, dtype=np.uint8)
+    assert (oracle.resize_cubic_bgr8(flat, 47, 71) == 200).all()
+    ofs, coef = oracle.resize_cubic_tables(100, 200)
+    # d = 2k: f = k - 0.25 -> s = k - 1, x = 0.75; d = 2k + 1: f = k + 0.25 -> s = k, x = 0.25
+    w = lambda x: np.array([((-0.75 * (x + 1) + 3.75) * (x + 1) - 6) * (x + 1) + 3, (1.25 * x - 2.25) * x * x + 1,
+                            (1.25 * (1 - x) - 2.25) * (1 - x) ** 2 + 1, 0.0])
+    for d, (s, x) in {10: (4, 0.75), 11: (5, 0.25)}.items():
+        ww = w(x); ww[3] = 1 - ww[:3].sum()
+        assert ofs[d] == s and np.array_equal(coef[d], np.rint(ww * 2048).astype(np.int16))
+    assert (coef.sum(axis=1) == 2048).all()
