@@ -607,14 +607,28 @@ __global__ __launch_bounds__(256) void resize_cubic_kernel(ResizeArgs a)
     for (int j = 0; j < 4; ++j) sx[j] = min(max(xo - 1 + j, 0), a.scols - 1) * 3;
     const unsigned char *S = a.src + (long long)n * a.src_plane;
     int h[4][3];
+    const bool inner = xo >= 1 && xo + 2 <= a.scols - 1;             // the four taps are 12 contiguous bytes
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const unsigned char *row = S + (long long)min(max(yo - 1 + k, 0), a.srows - 1) * a.src_pitch;
+        unsigned char px[12];
+        if (inner) {                                                 // three byte-aligned dword loads instead of twelve byte loads
+            typedef unsigned int u32u __attribute__((aligned(1)));
+            const u32u *q = reinterpret_cast<const u32u *>(row + sx[0]);
+            const unsigned int w0 = q[0], w1 = q[1], w2 = q[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { px[i] = (unsigned char)(w0 >> (8 * i)); px[4 + i] = (unsigned char)(w1 >> (8 * i)); px[8 + i] = (unsigned char)(w2 >> (8 * i)); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[3 * j + c] = row[sx[j] + c];
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             int v = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v += (int)row[sx[j] + c] * (int)al[j];
+            for (int j = 0; j < 4; ++j) v += (int)px[3 * j + c] * (int)al[j];
             h[k][c] = v;
         }
     }
