@@ -286,10 +286,24 @@ def host_call_rate(ctx, cols, rows, levels, win, reps=5):
     with LKFLOW_OPT_PIN_HOST (the loop's re-used buffers page-locked in place once: true DMA)."""
     import numpy as np
     import synth
-    a, b = synth.frame_pair(rows, cols, seed=99)
-    a8 = np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)
-    b8 = np.clip(np.rint(b * 255.0), 0, 255).astype(np.uint8)
-    u, v = np.empty((rows, cols)), np.empty((rows, cols))
+    import mmap
+    a_np, b_np = synth.frame_pair(rows, cols, seed=99)
+    keep = []
+
+    def fresh(shape, dtype, src=None):
+        """An array on its own anonymous mapping -- what a C++ caller's cv::Mat::create / malloc returns for a 16 MB plane.
+        (H2D from the arrays NumPy hands back after its own computations, recycled ranges of the Python heap, runs at
+        16-23 GB/s on the GPU box instead of the link's 55 GB/s: tools/host_call_py.py, tools/ubench/host_call.cpp and
+        profiles/r02_h_host_call.txt -- the same calls from C take 1.4 ms.  That case is reported as numpy_heap_arrays.)"""
+        m = mmap.mmap(-1, int(np.prod(shape)) * np.dtype(dtype).itemsize)
+        keep.append(m)
+        arr = np.frombuffer(m, dtype=dtype).reshape(shape)
+        arr[...] = 0 if src is None else src
+        return arr
+    a, b = fresh((rows, cols), np.float64, a_np), fresh((rows, cols), np.float64, b_np)
+    a8 = fresh((rows, cols), np.uint8, np.clip(np.rint(a_np * 255.0), 0, 255).astype(np.uint8))
+    b8 = fresh((rows, cols), np.uint8, np.clip(np.rint(b_np * 255.0), 0, 255).astype(np.uint8))
+    u, v = fresh((rows, cols), np.float64), fresh((rows, cols), np.float64)
 
     def timed(x, y):
         ctx.enqueue_pair(x, y, levels, win, out=(u, v)); ctx.wait()
@@ -302,6 +316,8 @@ def host_call_rate(ctx, cols, rows, levels, win, reps=5):
                note="rank 0 only, extra: 2 planes H2D + 2 planes D2H from pageable memory around the same kernels "
                     "(lkflow_enqueue_pair_f64 + lkflow_wait = lkflow_compute_f64)")
     out["u8_in"] = dict(timed(a8, b8), bytes_over_pcie_per_pair=2 * rows * cols + 2 * rows * cols * 8)
+    out["numpy_heap_arrays"] = dict(timed(a_np, b_np), note="f64 call again with the input arrays exactly as NumPy's own "
+                                    "computation left them on the Python heap (see the docstring of fresh())")
     ctx.pin_host(True)
     try:
         out["pinned"] = {"f64_in": timed(a, b), "u8_in": timed(a8, b8),
