@@ -576,16 +576,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
-    stream_extra = None
-    if dist is not None and not args.no_extras and os.environ.get("LKFLOW_BENCH_NO_STREAM_EXTRA") != "1":
-        del prev, nxt, U, V
-        torch.cuda.empty_cache()
-        try:
-            stream_extra = stream_sharding_extra(lkf, torch, dist, synth, ctx, args.config, dev, rank, world)
-        except Exception as e:                               # noqa: BLE001 -- an extra must never cost the headline line
-            stream_extra = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
-        prev = nxt = U = V = None
-
     if rank == 0:
         px_per_step = P * rows * cols * world
         value = px_per_step * args.steps / dt / 1e6
@@ -627,8 +617,35 @@ def main():
             names = {0: "pyrdown", 1: "warp", 2: "lk"}
             out["stage_ms_per_step"] = {f"{names[s]}_L{l}": round(ms / args.steps, 4)
                                         for (s, l), (ms, n) in sorted(prof.items())}
-        if stream_extra is not None:
+
+    # N > 1: the frame-queue mode of north_star as an extra object.  It is the only part of this file that moves data
+    # between ranks, and it must never cost the headline line: rank 0's line is complete BEFORE it starts, and a deadline
+    # timer on every rank prints that line (rank 0) and ends the process if a rank gets stuck in a send / recv / barrier
+    # (RCCL's own watchdog would abort the job after the process-group timeout and the line would be lost).
+    if dist is not None and not args.no_extras and os.environ.get("LKFLOW_BENCH_NO_STREAM_EXTRA") != "1":
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["stream_sharding"] = {"error": "deadline: a rank did not finish the stream extra in time"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        wd = threading.Timer(float(os.environ.get("LKFLOW_BENCH_STREAM_EXTRA_DEADLINE_S", "150")), give_up)
+        wd.daemon = True
+        wd.start()
+        del prev, nxt, U, V
+        torch.cuda.empty_cache()
+        stream_extra = None
+        try:
+            stream_extra = stream_sharding_extra(lkf, torch, dist, synth, ctx, args.config, dev, rank, world)
+        except Exception as e:                               # noqa: BLE001 -- an extra must never cost the headline line
+            stream_extra = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
+        wd.cancel()
+        prev = nxt = U = V = None
+        if rank == 0 and stream_extra is not None:
             out["stream_sharding"] = stream_extra
+
+    if rank == 0:
         if world == 1 and K == 1 and not args.graph and P >= 8 and not args.no_extras:
             out["pipelined"] = pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, local_rank, world)
         if world == 1 and not args.no_extras:
