@@ -25,11 +25,13 @@ def _omp_oracle(oracle, a, b, levels, win):
     return oracle.omp_coarse_to_fine(a, b, levels, win, 1)
 
 
-@pytest.mark.parametrize("rows,cols,levels,win,seed", [(2160, 3840, 5, 21, 7), (4320, 7680, 5, 31, 9)],
-                         ids=["config2_4k_L5_w21", "config4_8k_L5_w31"])
+@pytest.mark.parametrize("rows,cols,levels,win,seed", [(2160, 3840, 5, 21, 7), (4320, 7680, 5, 31, 9), (2448, 3264, 3, 15, 11)],
+                         ids=["config2_4k_L5_w21", "config4_8k_L5_w31", "config0_hand_shape_3264x2448_L3_w15"])
 def test_full_size_config_vs_oracle(gpu_ctx, oracle, rows, cols, levels, win, seed):
     """BASELINE configs 2 and 4 at FULL size, one pair, against the CPU oracle: pins pyrDown, warp and LK at
-    these sizes (the march == per-pixel tests share pyrDown and warp between their two legs)."""
+    these sizes (the march == per-pixel tests share pyrDown and warp between their two legs).  Config 0's frame
+    shape (testdata/hand1.jpg, 3264x2448, L3 w15) at full size too, on synthetic frames: the hand images themselves
+    are checked as the committed 816x612 crop (tests/test_gpu_parity.py), a 16 MB fixture would not be "small"."""
     import synth
     a, b = synth.frame_pair(rows, cols, seed=seed)
     u, v = gpu_ctx.computeFlow(a, b, levels, win)
