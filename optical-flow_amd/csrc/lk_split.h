@@ -21,8 +21,9 @@
 //     the two window sums go back through LDS (one 16-byte store).
 //   * 2 "B" (back) waves, one column per lane: the five window sums of a row come back from LDS (one
 //     ds_read_b64 per field) -> 2 x 2 solve with true fp64 divisions, /0 -> 0, "+= pyrUp(coarse flow)" from
-//     register-carried coarse rows (taps fetched one step ahead), streaming store.  Pixels whose window is
-//     clipped by the image border are overwritten afterwards by lk_border_kernel (end of this file).
+//     register-carried coarse rows (taps fetched one step ahead), streaming store.  The frame of width R just inside
+//     the image (clipped windows, outermost ring) is never stored by B: lk_border_pixel writes it, in trailing
+//     workgroups of the same launch.
 //
 // The three stages run concurrently on different marched rows with double-buffered LDS planes; a pipeline STEP is
 // TWO marched rows (F: rows 2s, 2s+1; S: the two rows of step s-1; B: those of step s-2) and ends in ONE workgroup
@@ -133,12 +134,85 @@ __device__ __forceinline__ double split_tree(const A &v)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Clipped-window pixels of lk_split_kernel's output (SerialPyr.cpp:94-95: a pixel inside the outermost ring whose
+// WIN x WIN window leaves the image takes m(y,x) * WIN^2 for each of the five sums): the frame of width R just
+// inside the image INCLUDING the outermost ring (0 + pyrUp), one thread per pixel; the marching workgroups store none of
+// it, so there is no ordering between the two.  Runs as trailing workgroups of lk_split_kernel's own launch (default) or
+// as lk_border_kernel.  Same expressions as
+// the one-role kernels' clipped branch (lk_products_at, lk_solve, pyrup_at).
+// ------------------------------------------------------------------------------------------------
+template <bool HAS_UP, bool FW = false>
+__device__ __forceinline__ void lk_border_pixel(const LKArgs &a, int win, long long idx, int pair)
+{
+    const int R = win / 2, H = a.H, W = a.W;
+    int y, x;
+    const int nr = min(2 * R, H);                            // rows of the top + bottom bands
+    if (idx < (long long)nr * W) {
+        const int k = (int)(idx / W);
+        x = (int)(idx % W);
+        y = (H <= 2 * R) ? k : (k < R ? k : H - 2 * R + k);
+    } else {                                                 // left + right bands of the rows in between
+        const long long k2 = idx - (long long)nr * W;
+        const int nc = min(2 * R, W);
+        if (H <= 2 * R || k2 >= (long long)(H - 2 * R) * nc) return;
+        y = R + (int)(k2 / nc);
+        const int c = (int)(k2 % nc);
+        x = (W <= 2 * R) ? c : (c < R ? c : W - 2 * R + c);
+    }
+    if (!((y - R < 0) || (y + R > H - 1) || (x - R < 0) || (x + R > W - 1))) return;      // full window: the main kernel's (never mapped here)
+    const bool ring = !(y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2);                    // outermost ring: 0 (+ pyrUp)
+    double S[5], u = 0.0, v = 0.0;
+    if (!ring) {
+    if constexpr (FW) {
+        // fused warp: a.i1 / a.i2 are the UN-warped level images; the four warped taps of both images are made here
+        // (cv::pyrUp of the coarse flow at the tap, float map, remap: warp_kernel's arithmetic)
+        const double *I1 = a.i1.at(pair), *I2 = a.i2.at(pair), *cu = a.cu.at(pair), *cv = a.cv.at(pair);
+        const int ym = r101(y - 1, H), xm = r101(x - 1, W);
+        auto warped = [&](int yy, int xx, double &w1, double &w2) {
+            const float hx = (float)pyrup_at(cu, a.cu.pitch, H >> 1, W >> 1, yy, xx) / 2;
+            const float hy = (float)pyrup_at(cv, a.cv.pitch, H >> 1, W >> 1, yy, xx) / 2;
+            w1 = remap_bilinear(I1, (int)a.i1.pitch, H, W, (float)xx + hx, (float)yy + hy);
+            w2 = remap_bilinear(I2, (int)a.i2.pitch, H, W, (float)xx - hx, (float)yy - hy);
+        };
+        double a00, a01, a10, a11, b00, b01, b10, b11;
+        warped(ym, xm, a00, b00); warped(ym, x, a01, b01); warped(y, xm, a10, b10); warped(y, x, a11, b11);
+        lk_products(a00, a01, a10, a11, b00, b01, b10, b11, S);
+    } else
+    lk_products_at(a.i1.at(pair), a.i2.at(pair), a.i1.pitch, H, W, y, x, S);
+    for (int f = 0; f < 5; ++f) S[f] = S[f] * (double)(win * win);
+    lk_solve(S, u, v);
+    }
+    if (HAS_UP) {
+        u += pyrup_at(a.cu.at(pair), a.cu.pitch, H >> 1, W >> 1, y, x);
+        v += pyrup_at(a.cv.at(pair), a.cv.pitch, H >> 1, W >> 1, y, x);
+    }
+    a.u.at(pair)[(long long)y * a.u.pitch + x] = u;
+    a.v.at(pair)[(long long)y * a.v.pitch + x] = v;
+}
+
+
+// the same as a launch of its own (LKFLOW_BORDER_MERGED=0, A/B): grid (frame pixels / 256, pairs)
+template <bool HAS_UP, bool FW = false>
+__global__ __launch_bounds__(256) void lk_border_kernel(LKArgs a, int win)
+{
+    lk_border_pixel<HAS_UP, FW>(a, win, (long long)blockIdx.x * 256 + threadIdx.x, blockIdx.y);
+}
+
 template <int WIN, int K, bool HAS_UP, bool FW = false>
 __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::WPE)) void lk_split_kernel(LKArgs a)
 {
     using C = SplitCfg<WIN, K, FW>;
     static_assert(!FW || HAS_UP, "the fused warp needs a coarser level");
     constexpr int R = C::R, XO = C::XO, KH = C::KH, PADJ = C::PADJ, PF = C::PF, UN = C::UN, HL = C::HL;
+    if (a.nmain && blockIdx.x >= a.nmain) {
+        // trailing workgroups of the launch: the frame of width R just inside the image (lk_border_pixel above), one
+        // pixel per thread.  They are dispatched last, into the slots the marching workgroups free as they finish, so
+        // the frame costs neither a launch of its own nor the idle tail of one.
+        const unsigned bb = blockIdx.x - a.nmain;
+        lk_border_pixel<HAS_UP, FW>(a, WIN, (long long)(bb % a.nbb) * C::NT + threadIdx.x, (int)(bb / a.nbb));
+        return;
+    }
     __shared__ __attribute__((aligned(16))) double s_prod[2][2][5][C::PROD_D];   // [step parity][row of the step][field]: (a, b) products of every column pair
     __shared__ double s_q[C::QSUM ? 2 : 1][C::QSUM ? 2 : 1][C::QSUM ? 5 : 1][C::QSUM ? C::NJP : 1];   // the pair sums a + b (index = chunk), if F publishes them
     __shared__ __attribute__((aligned(16))) double s_sums[2][2][5][C::SUMS_D];
@@ -168,7 +242,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
 #ifdef LK_SPLIT_NO_XCD
     unsigned tile = blockIdx.x;
 #else
-    unsigned tile = xcd_tile_id(blockIdx.x, gridDim.x);
+    unsigned tile = xcd_tile_id(blockIdx.x, a.nmain ? a.nmain : gridDim.x);
 #endif
     const int bx = tile % a.gx; tile /= a.gx;
     const int by = tile % a.gy;
@@ -560,8 +634,9 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         const int t = ltid;                          // block column 0 .. TXC-1
         const int x = x0 + t;
         const int xc = min(max(x, 0), W - 1);
-        const bool is_out = t >= HL && t < HL + XO && x < W;
-        const bool inner_x = x >= 1 && x <= W - 2;
+        // output column of this block that is NOT in the frame of width R just inside the image: the frame (clipped
+        // windows and the outermost ring) belongs to lk_border_kernel, which runs concurrently on a side stream
+        const bool is_out = t >= HL && t < HL + XO && x >= R && x < W - R;
         const int s_slot = KH == 1 ? t : 2 * (((t % K) >> 1) * C::SSTR + t / K) + (t & 1);
 
         [[maybe_unused]] UpSel1 us{};
@@ -617,23 +692,24 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // slot; LDS step parity = (p + R) & 1).  Straight-line: every vector-memory instruction is issued
         // unconditionally (see the file header); the two solves are independent and interleave.
         const int vo_lane = is_out ? vxo : (int)0x80000000;   // out of range: the store is dropped
-        auto solve5 = [&](const double (&S)[5], bool inner, double &u, double &v) __attribute__((always_inline)) {
+        auto solve5 = [&](const double (&S)[5], double &u, double &v) __attribute__((always_inline)) {
 #ifdef LK_SPLIT_ABL_B   /* timing-only ablation build: no solve */
-            u = inner ? S[0] + S[2] + S[4] : 0.0; v = inner ? S[1] + S[3] : 0.0; return;
+            u = S[0] + S[2] + S[4]; v = S[1] + S[3]; return;
 #endif
             const double det = S[0] * S[1] - S[2] * S[2];
             const double un = S[2] * S[4] - S[1] * S[3];
             const double vn = S[3] * S[2] - S[0] * S[4];
-            const bool nz = det != 0.0 && inner;            // cv::divide: x/0 -> 0; outermost ring: 0
+            const bool nz = det != 0.0;                     // cv::divide: x/0 -> 0
             const double qu = un / det, qv = vn / det;
             u = nz ? qu : 0.0;
             v = nz ? qv : 0.0;
         };
         // (pixels whose window is clipped by the image border get m(y,x) * WIN^2 instead of a window sum,
-        // SerialPyr.cpp:94-95: lk_border_kernel overwrites them after this kernel -- a load under a condition in
-        // this loop would make hipcc's vmcnt counting conservative and drain the wave's stores at every step)
-        auto solve_row = [&](int y, const double (&S)[5], double &u, double &v) __attribute__((always_inline)) {
-            solve5(S, inner_x && y >= 1 && y <= H - 2, u, v);
+        // SerialPyr.cpp:94-95, and the outermost ring gets 0: lk_border_kernel writes that whole frame, this kernel
+        // stores none of it -- a load under a condition in this loop would make hipcc's vmcnt counting conservative
+        // and drain the wave's stores at every step)
+        auto solve_row = [&](int, const double (&S)[5], double &u, double &v) __attribute__((always_inline)) {
+            solve5(S, u, v);
         };
         auto bpair = [&](auto pc2, int p) __attribute__((always_inline)) {
             constexpr int P2 = decltype(pc2)::value;        // p mod TD
@@ -672,10 +748,13 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
 #ifdef LK_SPLIT_ABL_NOSTORE
             if (ue + ve + uo + vo == 12345.678) buf_st(rU, vo_lane, sou, ue);
 #else
-            buf_st(rU, vo_lane, sou, ue);
-            buf_st(rV, vo_lane, sov, ve);
-            buf_st(rU, vo_lane, sou + upb, uo);
-            buf_st(rV, vo_lane, sov + vpb, vo);
+            // rows of the frame (wave-uniform test): out-of-range offset, the store is dropped
+            const int voe = (y >= R && y < H - R) ? vo_lane : (int)0x80000000;
+            const int voo = (y + 1 >= R && y + 1 < H - R) ? vo_lane : (int)0x80000000;
+            buf_st(rU, voe, sou, ue);
+            buf_st(rV, voe, sov, ve);
+            buf_st(rU, voo, sou + upb, uo);
+            buf_st(rV, voo, sov + vpb, vo);
 #endif
             sou += 2 * upb; sov += 2 * vpb;
         };
@@ -854,60 +933,6 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         a.dbg[wid * 8 + 7] = wv;
     }
 #endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// Clipped-window pixels of lk_split_kernel's output (SerialPyr.cpp:94-95: a pixel inside the outermost ring whose
-// WIN x WIN window leaves the image takes m(y,x) * WIN^2 for each of the five sums): the frame of width R just
-// inside the image, one thread per pixel, launched after lk_split_kernel on the same stream.  Same expressions as
-// the one-role kernels' clipped branch (lk_products_at, lk_solve, pyrup_at).
-// ------------------------------------------------------------------------------------------------
-template <bool HAS_UP, bool FW = false>
-__global__ __launch_bounds__(256) void lk_border_kernel(LKArgs a, int win)
-{
-    const int R = win / 2, H = a.H, W = a.W, pair = blockIdx.y;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    int y, x;
-    const int nr = min(2 * R, H);                            // rows of the top + bottom bands
-    if (idx < (long long)nr * W) {
-        const int k = (int)(idx / W);
-        x = (int)(idx % W);
-        y = (H <= 2 * R) ? k : (k < R ? k : H - 2 * R + k);
-    } else {                                                 // left + right bands of the rows in between
-        const long long k2 = idx - (long long)nr * W;
-        const int nc = min(2 * R, W);
-        if (H <= 2 * R || k2 >= (long long)(H - 2 * R) * nc) return;
-        y = R + (int)(k2 / nc);
-        const int c = (int)(k2 % nc);
-        x = (W <= 2 * R) ? c : (c < R ? c : W - 2 * R + c);
-    }
-    if (!(y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2)) return;                          // outermost ring: 0 (+ pyrUp), done by the main kernel
-    if (!((y - R < 0) || (y + R > H - 1) || (x - R < 0) || (x + R > W - 1))) return;      // full window: done by the main kernel
-    double S[5], u, v;
-    if constexpr (FW) {
-        // fused warp: a.i1 / a.i2 are the UN-warped level images; the four warped taps of both images are made here
-        // (cv::pyrUp of the coarse flow at the tap, float map, remap: warp_kernel's arithmetic)
-        const double *I1 = a.i1.at(pair), *I2 = a.i2.at(pair), *cu = a.cu.at(pair), *cv = a.cv.at(pair);
-        const int ym = r101(y - 1, H), xm = r101(x - 1, W);
-        auto warped = [&](int yy, int xx, double &w1, double &w2) {
-            const float hx = (float)pyrup_at(cu, a.cu.pitch, H >> 1, W >> 1, yy, xx) / 2;
-            const float hy = (float)pyrup_at(cv, a.cv.pitch, H >> 1, W >> 1, yy, xx) / 2;
-            w1 = remap_bilinear(I1, (int)a.i1.pitch, H, W, (float)xx + hx, (float)yy + hy);
-            w2 = remap_bilinear(I2, (int)a.i2.pitch, H, W, (float)xx - hx, (float)yy - hy);
-        };
-        double a00, a01, a10, a11, b00, b01, b10, b11;
-        warped(ym, xm, a00, b00); warped(ym, x, a01, b01); warped(y, xm, a10, b10); warped(y, x, a11, b11);
-        lk_products(a00, a01, a10, a11, b00, b01, b10, b11, S);
-    } else
-    lk_products_at(a.i1.at(pair), a.i2.at(pair), a.i1.pitch, H, W, y, x, S);
-    for (int f = 0; f < 5; ++f) S[f] = S[f] * (double)(win * win);
-    lk_solve(S, u, v);
-    if (HAS_UP) {
-        u += pyrup_at(a.cu.at(pair), a.cu.pitch, H >> 1, W >> 1, y, x);
-        v += pyrup_at(a.cv.at(pair), a.cv.pitch, H >> 1, W >> 1, y, x);
-    }
-    a.u.at(pair)[(long long)y * a.u.pitch + x] = u;
-    a.v.at(pair)[(long long)y * a.v.pitch + x] = v;
 }
 
 }  // namespace lk

@@ -50,6 +50,9 @@ struct lkflow_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t own_stream = nullptr;
+    // fork / join for the clipped-window frame kernel, which runs beside the main LK kernel (created on first use)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string last_error;
     // options
     int impl = 0;
@@ -287,6 +290,41 @@ int launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStr
     return LKFLOW_OK;
 }
 
+// The frame of width R just inside the image (clipped windows, SerialPyr.cpp:94-95, and the outermost ring) is written
+// by lk_border_kernel and by nobody else, so it does not have to wait for the main LK kernel: it is forked onto the
+// context's side stream (both kernels depend on the warp before them only) and joined after the main launch.  The
+// fork / join is a pair of events, so it is captured into a HIP graph like any other dependency.
+// LKFLOW_BORDER_SIDE=0 (debug knob, A/B): same stream, in front of the main kernel.
+struct BorderFork {
+    lkflow_ctx *ctx; hipStream_t s, bs;
+    BorderFork(lkflow_ctx *c, hipStream_t st) : ctx(c), s(st), bs(st)
+    {
+        static const int side = getenv("LKFLOW_BORDER_SIDE") ? atoi(getenv("LKFLOW_BORDER_SIDE")) : 0;
+        if (!side) return;
+        if (!ctx->side_stream) {
+            if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                if (ctx->ev_fork) { (void)hipEventDestroy(ctx->ev_fork); ctx->ev_fork = nullptr; }
+                if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr; }
+                return;                                      // no side stream: the frame kernel runs in stream order
+            }
+        }
+        if (hipEventRecord(ctx->ev_fork, s) != hipSuccess || hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        bs = ctx->side_stream;
+    }
+    // after the frame kernel has been launched on bs and the main kernel on s
+    bool join()
+    {
+        if (bs == s) return true;
+        return hipEventRecord(ctx->ev_join, bs) == hipSuccess && hipStreamWaitEvent(s, ctx->ev_join, 0) == hipSuccess;
+    }
+};
+
 // Wave-specialised kernel (lk_split.h): K*64-column blocks, K PE waves + 5 window-sum waves
 template <int WIN, int K>
 int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
@@ -328,15 +366,29 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
         }
     }
 #endif
+    // the frame of clipped-window pixels (SerialPyr.cpp:94-95) and the outermost ring: frame pixels per pair
+    const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
+    const long long nfp = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
+    static const int merged = getenv("LKFLOW_BORDER_MERGED") ? atoi(getenv("LKFLOW_BORDER_MERGED")) : 1;   // debug knob (A/B)
+    const long long nbb = (nfp + C::NT - 1) / C::NT;
+    if (merged && (long long)grid.x + nbb * pairs <= 0x7fffffffLL) {
+        // as trailing workgroups of the main launch
+        a.nmain = grid.x; a.nbb = (unsigned)nbb;
+        grid.x += (unsigned)(nbb * pairs);
+        if (has_up) hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true>), grid, dim3(C::NT), 0, s, a);
+        else hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, false>), grid, dim3(C::NT), 0, s, a);
+        return LKFLOW_OK;
+    }
+    a.nmain = 0; a.nbb = 0;
+    BorderFork bf(ctx, s);
+    {   // as a launch of its own, in front of the main kernel (or beside it, on the side stream)
+        dim3 bg((unsigned)((nfp + 255) / 256), pairs);
+        if (has_up) hipLaunchKernelGGL((lk::lk_border_kernel<true>), bg, dim3(256), 0, bf.bs, a, WIN);
+        else hipLaunchKernelGGL((lk::lk_border_kernel<false>), bg, dim3(256), 0, bf.bs, a, WIN);
+    }
     if (has_up) hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true>), grid, dim3(C::NT), 0, s, a);
     else hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, false>), grid, dim3(C::NT), 0, s, a);
-    {   // the frame of clipped-window pixels (SerialPyr.cpp:94-95), overwritten in stream order
-        const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
-        const long long n = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
-        dim3 bg((unsigned)((n + 255) / 256), pairs);
-        if (has_up) hipLaunchKernelGGL((lk::lk_border_kernel<true>), bg, dim3(256), 0, s, a, WIN);
-        else hipLaunchKernelGGL((lk::lk_border_kernel<false>), bg, dim3(256), 0, s, a, WIN);
-    }
+    if (!bf.join()) { hip_ok(ctx, hipGetLastError(), "frame kernel join"); return LKFLOW_E_HIP; }
     return LKFLOW_OK;
 }
 
@@ -365,12 +417,15 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
     a.th = th;
     a.gx = gx; a.gy = (a.H + th - 1) / th;
     if ((long long)a.gx * a.gy * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
-    hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true, true>), dim3((unsigned)(a.gx * a.gy * pairs)), dim3(C::NT), 0, s, a);
-    {   // the frame of clipped-window pixels, overwritten in stream order (its warped taps are made on the fly)
+    a.nmain = 0; a.nbb = 0;
+    BorderFork bf(ctx, s);
+    {   // the frame of clipped-window pixels and the outermost ring (its warped taps are made on the fly)
         const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
         const long long n = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
-        hipLaunchKernelGGL((lk::lk_border_kernel<true, true>), dim3((unsigned)((n + 255) / 256), pairs), dim3(256), 0, s, a, WIN);
+        hipLaunchKernelGGL((lk::lk_border_kernel<true, true>), dim3((unsigned)((n + 255) / 256), pairs), dim3(256), 0, bf.bs, a, WIN);
     }
+    hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true, true>), dim3((unsigned)(a.gx * a.gy * pairs)), dim3(C::NT), 0, s, a);
+    if (!bf.join()) { hip_ok(ctx, hipGetLastError(), "frame kernel join"); return LKFLOW_E_HIP; }
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }
@@ -651,6 +706,9 @@ void lkflow_ctx_destroy(lkflow_ctx *ctx)
     for (auto &q : ctx->pins) unpin_host_range(q.p);
     for (auto &r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
