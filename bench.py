@@ -118,7 +118,7 @@ def roofline_objects(lkf, name, cols, rows, levels, win, P, pairs_per_launch, lk
     path_achieved = b_alg * P * steps / dt          # per GPU
     roof = {
         "kernel": f"{kname} (LK at pyramid level 0" + (", warp fused" if "w3x2f" in kname else "") +
-                  (" + lk::lk_border_kernel, the clipped-window frame, inside the same HIP-event bracket" if "lk_split" in kname else "") + ")",
+                  (", incl. the trailing workgroups that write the clipped-window frame" if "lk_split" in kname else "") + ")",
         "bound": "hbm",
         "achieved": round(achieved / 1e9, 2),
         "peak": HBM_PEAK / 1e9,
