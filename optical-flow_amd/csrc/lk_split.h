@@ -143,32 +143,35 @@ __device__ __forceinline__ double split_tree(const A &v)
 // the one-role kernels' clipped branch (lk_products_at, lk_solve, pyrup_at).
 // ------------------------------------------------------------------------------------------------
 template <bool HAS_UP, bool FW = false>
-__device__ __forceinline__ void lk_border_pixel(const LKArgs &a, int win, long long idx, int pair)
+__device__ __forceinline__ void lk_border_pixel(const LKArgs &a, int win, unsigned idx, int pair)
 {
+    // (host-checked: the frame of one plane has fewer than 2^31 pixels -- 32-bit index arithmetic; a 64-bit division
+    // costs ~100 vector instructions and this function ran three of them)
     const int R = win / 2, H = a.H, W = a.W;
     int y, x;
-    const int nr = min(2 * R, H);                            // rows of the top + bottom bands
-    if (idx < (long long)nr * W) {
-        const int k = (int)(idx / W);
-        x = (int)(idx % W);
-        y = (H <= 2 * R) ? k : (k < R ? k : H - 2 * R + k);
+    const unsigned nr = (unsigned)min(2 * R, H);             // rows of the top + bottom bands
+    if (idx < nr * (unsigned)W) {
+        const unsigned k = idx / (unsigned)W;
+        x = (int)(idx - k * (unsigned)W);
+        y = (H <= 2 * R) ? (int)k : ((int)k < R ? (int)k : H - 2 * R + (int)k);
     } else {                                                 // left + right bands of the rows in between
-        const long long k2 = idx - (long long)nr * W;
-        const int nc = min(2 * R, W);
-        if (H <= 2 * R || k2 >= (long long)(H - 2 * R) * nc) return;
-        y = R + (int)(k2 / nc);
-        const int c = (int)(k2 % nc);
+        const unsigned k2 = idx - nr * (unsigned)W;
+        const unsigned nc = (unsigned)min(2 * R, W);
+        if (H <= 2 * R || k2 >= (unsigned)(H - 2 * R) * nc) return;
+        const unsigned q = k2 / nc;
+        y = R + (int)q;
+        const int c = (int)(k2 - q * nc);
         x = (W <= 2 * R) ? c : (c < R ? c : W - 2 * R + c);
     }
     if (!((y - R < 0) || (y + R > H - 1) || (x - R < 0) || (x + R > W - 1))) return;      // full window: the main kernel's (never mapped here)
     const bool ring = !(y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2);                    // outermost ring: 0 (+ pyrUp)
     double S[5], u = 0.0, v = 0.0;
-    if (!ring) {
     if constexpr (FW) {
+      if (!ring) {
         // fused warp: a.i1 / a.i2 are the UN-warped level images; the four warped taps of both images are made here
         // (cv::pyrUp of the coarse flow at the tap, float map, remap: warp_kernel's arithmetic)
         const double *I1 = a.i1.at(pair), *I2 = a.i2.at(pair), *cu = a.cu.at(pair), *cv = a.cv.at(pair);
-        const int ym = r101(y - 1, H), xm = r101(x - 1, W);
+        const int ym = y - 1, xm = x - 1;
         auto warped = [&](int yy, int xx, double &w1, double &w2) {
             const float hx = (float)pyrup_at(cu, a.cu.pitch, H >> 1, W >> 1, yy, xx) / 2;
             const float hy = (float)pyrup_at(cv, a.cv.pitch, H >> 1, W >> 1, yy, xx) / 2;
@@ -178,10 +181,61 @@ __device__ __forceinline__ void lk_border_pixel(const LKArgs &a, int win, long l
         double a00, a01, a10, a11, b00, b01, b10, b11;
         warped(ym, xm, a00, b00); warped(ym, x, a01, b01); warped(y, xm, a10, b10); warped(y, x, a11, b11);
         lk_products(a00, a01, a10, a11, b00, b01, b10, b11, S);
-    } else
-    lk_products_at(a.i1.at(pair), a.i2.at(pair), a.i1.pitch, H, W, y, x, S);
-    for (int f = 0; f < 5; ++f) S[f] = S[f] * (double)(win * win);
-    lk_solve(S, u, v);
+        for (int f = 0; f < 5; ++f) S[f] = S[f] * (double)(win * win);
+        lk_solve(S, u, v);
+      }
+    } else {
+        // Straight-line: every load is issued up front from an address that is valid for ring pixels too (their products
+        // are computed and dropped), so that the image taps and the coarse-flow taps are in flight together.  A pixel
+        // inside the ring has y - 1 >= 0 and x - 1 >= 0: no reflection.
+        const int yc = max(y, 1), xc = max(x, 1);
+        const double *r1a = a.i1.at(pair) + (long long)yc * a.i1.pitch + xc, *r0a = r1a - a.i1.pitch;
+        const double *r1b = a.i2.at(pair) + (long long)yc * a.i2.pitch + xc, *r0b = r1b - a.i2.pitch;
+        const double a00 = r0a[-1], a01 = r0a[0], a10 = r1a[-1], a11 = r1a[0];
+        const double b00 = r0b[-1], b01 = r0b[0], b10 = r1b[-1], b11 = r1b[0];
+        [[maybe_unused]] double tu[3][3], tv[3][3];
+        [[maybe_unused]] UpSel1 us{};
+        if constexpr (HAS_UP) {
+            // cv::pyrUp of the coarse flow at (y, x) with the main kernel's branch-free taps (make_upsel1 / pyrup_h1v:
+            // the same roundings as pyrup_h) on the coarse rows s(i-1), s(i), s(i+1), i = y >> 1 (clamped as pyrup_at's
+            // reflections come out: s(-1) = min(1, Hc-1), s(Hc) = Hc-1)
+            const int Hc = H >> 1, Wc = W >> 1, i = y >> 1;
+            us = make_upsel1(x, Wc);
+            const double *cu = a.cu.at(pair), *cv = a.cv.at(pair);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int k = i - 1 + q;
+                const int sr = k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k);
+                const char *pu = reinterpret_cast<const char *>(cu + (long long)sr * a.cu.pitch);
+                const char *pv = reinterpret_cast<const char *>(cv + (long long)sr * a.cv.pitch);
+                tu[q][0] = *reinterpret_cast<const double *>(pu + us.jm); tu[q][1] = *reinterpret_cast<const double *>(pu + us.jc);
+                tu[q][2] = *reinterpret_cast<const double *>(pu + us.jp);
+                tv[q][0] = *reinterpret_cast<const double *>(pv + us.jm); tv[q][1] = *reinterpret_cast<const double *>(pv + us.jc);
+                tv[q][2] = *reinterpret_cast<const double *>(pv + us.jp);
+            }
+        }
+        lk_products(a00, a01, a10, a11, b00, b01, b10, b11, S);
+        for (int f = 0; f < 5; ++f) S[f] = S[f] * (double)(win * win);
+        double us_, vs_;
+        lk_solve(S, us_, vs_);
+        u = ring ? 0.0 : us_;
+        v = ring ? 0.0 : vs_;
+        if constexpr (HAS_UP) {
+            double hu[3], hv[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                hu[q] = pyrup_h1v(tu[q][0], tu[q][1], tu[q][2], us);
+                hv[q] = pyrup_h1v(tv[q][0], tv[q][1], tv[q][2], us);
+            }
+            const bool odd = (y & 1) != 0;
+            const double ue = (hu[0] + hu[1] * 6 + hu[2]) * (1.0 / 64), uo = ((hu[1] + hu[2]) * 4) * (1.0 / 64);
+            const double ve = (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64), vo = ((hv[1] + hv[2]) * 4) * (1.0 / 64);
+            u += odd ? uo : ue;
+            v += odd ? vo : ve;
+        }
+        a.u.at(pair)[(long long)y * a.u.pitch + x] = u;
+        a.v.at(pair)[(long long)y * a.v.pitch + x] = v;
+        return;
     }
     if (HAS_UP) {
         u += pyrup_at(a.cu.at(pair), a.cu.pitch, H >> 1, W >> 1, y, x);
@@ -191,12 +245,11 @@ __device__ __forceinline__ void lk_border_pixel(const LKArgs &a, int win, long l
     a.v.at(pair)[(long long)y * a.v.pitch + x] = v;
 }
 
-
 // the same as a launch of its own (LKFLOW_BORDER_MERGED=0, A/B): grid (frame pixels / 256, pairs)
 template <bool HAS_UP, bool FW = false>
 __global__ __launch_bounds__(256) void lk_border_kernel(LKArgs a, int win)
 {
-    lk_border_pixel<HAS_UP, FW>(a, win, (long long)blockIdx.x * 256 + threadIdx.x, blockIdx.y);
+    lk_border_pixel<HAS_UP, FW>(a, win, blockIdx.x * 256u + threadIdx.x, blockIdx.y);
 }
 
 template <int WIN, int K, bool HAS_UP, bool FW = false>
@@ -209,8 +262,10 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // trailing workgroups of the launch: the frame of width R just inside the image (lk_border_pixel above), one
         // pixel per thread.  They are dispatched last, into the slots the marching workgroups free as they finish, so
         // the frame costs neither a launch of its own nor the idle tail of one.
+#ifndef LK_SPLIT_ABL_NOFRAME   /* timing-only ablation build: the frame workgroups return at once (results are wrong) */
         const unsigned bb = blockIdx.x - a.nmain;
-        lk_border_pixel<HAS_UP, FW>(a, WIN, (long long)(bb % a.nbb) * C::NT + threadIdx.x, (int)(bb / a.nbb));
+        lk_border_pixel<HAS_UP, FW>(a, WIN, (bb % a.nbb) * (unsigned)C::NT + threadIdx.x, (int)(bb / a.nbb));
+#endif
         return;
     }
     __shared__ __attribute__((aligned(16))) double s_prod[2][2][5][C::PROD_D];   // [step parity][row of the step][field]: (a, b) products of every column pair

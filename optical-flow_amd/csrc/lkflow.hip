@@ -369,6 +369,7 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
     // the frame of clipped-window pixels (SerialPyr.cpp:94-95) and the outermost ring: frame pixels per pair
     const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
     const long long nfp = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
+    if (nfp + 2 * C::NT >= 0x7fffffffLL) return LKFLOW_E_ARG;   // (the frame code indexes the pixels of one plane's frame with 32 bits)
     static const int merged = getenv("LKFLOW_BORDER_MERGED") ? atoi(getenv("LKFLOW_BORDER_MERGED")) : 1;   // debug knob (A/B)
     const long long nbb = (nfp + C::NT - 1) / C::NT;
     if (merged && (long long)grid.x + nbb * pairs <= 0x7fffffffLL) {
@@ -422,6 +423,7 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
     {   // the frame of clipped-window pixels and the outermost ring (its warped taps are made on the fly)
         const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
         const long long n = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
+        if (n + 512 >= 0x7fffffffLL) return LKFLOW_E_ARG;
         hipLaunchKernelGGL((lk::lk_border_kernel<true, true>), dim3((unsigned)((n + 255) / 256), pairs), dim3(256), 0, bf.bs, a, WIN);
     }
     hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true, true>), dim3((unsigned)(a.gx * a.gy * pairs)), dim3(C::NT), 0, s, a);
