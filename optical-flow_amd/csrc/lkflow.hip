@@ -666,7 +666,7 @@ int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok,
     if (win == 3 && has_up && fused_ok && !no_fused && cols >= 2 && !(cols & 1) && !(rows & 1)) snprintf(buf, n, "lk::lk_w3x2f_kernel");
     else if (win == 3 && !no_x2 && cols >= 2 && !(cols & 1)) snprintf(buf, n, "lk::lk_w3x2_kernel<%s>", up);
     else if (win == 3 && !no_w3) snprintf(buf, n, "lk::lk_march3_kernel<3, 64, %s>", up);
-    else if (split_applies(win, cols, rows)) snprintf(buf, n, "lk::lk_split_kernel<%d, 2, %s>", win, up);
+    else if (split_applies(win, cols, rows)) snprintf(buf, n, "lk::lk_split_kernel<%d, 2, %s, false>", win, up);   // (..., true> with LKFLOW_OPT_FUSE_WARP)
     else {
         const int R = win / 2;
         const long long c128 = (long long)((cols + (128 - 2 * R) - 1) / (128 - 2 * R)) * 128;

@@ -36,8 +36,11 @@ def test_committed_pmc_traffic_is_usable_by_bench():
     cols, rows, levels, win, pairs = bench.CONFIGS["1080p"]
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
         import json
-        names = [k for k in json.load(fh) if k.startswith("lk::lk_") and k.endswith(", true>")]
+        names = [k for k in json.load(fh) if k.startswith("lk::lk_") and ", true" in k]     # HAS_UP instantiations
     assert names, "no level-0 LK kernel in profiles/pmc_traffic.json"
+    sys.path.insert(0, os.path.join(ROOT, "optical-flow_amd"))
+    import lkflow_amd                                        # the name bench.py looks up is the one rocprofv3 printed
+    assert lkflow_amd.lk_kernel_name(rows, cols, win, has_up=True) in names
     alg = bench.lk0_bytes_per_pair(cols, rows, levels) * pairs
     ts = [bench.measured_traffic(k, cols, rows, pairs) for k in names]
     assert any(t is not None and alg <= t <= 2 * alg for t in ts)

@@ -9,4 +9,4 @@ for P in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUP
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python3 $R/bench.py --no-extras "$@" > $OUT/p$i.log 2>&1 || tail -3 $OUT/p$i.log
   i=$((i+1))
 done
-python3 $R/tools/pmc_summary.py $OUT | grep -A14 "lk_split_kernel<15, 2, true>"
+python3 $R/tools/pmc_summary.py $OUT | grep -A14 "lk_split_kernel<15, 2, true, false>"

@@ -27,4 +27,4 @@ for cfg in 1080p 4k webcam; do
   cp gpurun_out/pmc_${TAG}_${cfg}_traffic.json $OUT/${TAG}_${cfg}_pmc_traffic.json
   rm -rf gpurun_out/pmc_${TAG}_$cfg
 done
-grep -A18 "lk_split_kernel<15, 2, true>" $OUT/${TAG}_1080p_pmc_summary.txt | head -30
+grep -A18 "lk_split_kernel<15, 2, true, false>" $OUT/${TAG}_1080p_pmc_summary.txt | head -30
