@@ -284,6 +284,13 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
 #pragma unroll
     for (int q = 0; q < C::NW; ++q) wv_ = (pw == q) ? kPerm[q] : wv_;
     const int wv = __builtin_amdgcn_readfirstlane(wv_);
+#elif defined(LK_SPLIT_ALT_BIT)
+    // Every other workgroup (bit LK_SPLIT_ALT_BIT of the workgroup index) swaps the roles of its last two waves: F, the
+    // wave with by far the longest instruction stream, then sits on SIMD 2 instead of SIMD 3 (waves are dealt to the
+    // SIMDs round-robin), so that the two workgroups that share a CU do not stack both F waves on one SIMD.
+    const int pw = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool alt = !FW && ((blockIdx.x >> LK_SPLIT_ALT_BIT) & 1u) != 0;
+    const int wv = (alt && pw >= C::NB + 4) ? 2 * C::NB + 9 - pw : pw;
 #else
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 #endif
