@@ -228,7 +228,12 @@ int blocks_per_cu(lkflow_ctx *ctx, Kern kern, int threads)
 
 // Rows per block: every block marches th + 2R rows and blocks run in rounds of `slots` resident
 // blocks -> minimise rounds * (th + 2R + fixed cost) over the number of row strips.
-inline int pick_tile_rows(int H, int R, long long blocks_per_strip, long long slots)
+// lone_cus > 0 (the wave-specialised kernel at two workgroups per CU): a last, partial round that leaves at most one
+// workgroup on every CU costs 0.62 of a full one -- a workgroup that has its CU to itself steps 1.6 times as fast as one
+// of a pair (one workgroup per CU = +25 % time for the same work).  Measured on 32 x 1080p, 15 x 15
+// (tools/sweep_lk_th2.py, profiles/r02_i_lk_strip_height_repeat.txt): 4.5 rounds of 270-row strips 0.645 ms against
+// 0.671 ms for the 9 whole rounds of 136-row strips that the whole-rounds rule picks.
+inline int pick_tile_rows(int H, int R, long long blocks_per_strip, long long slots, long long lone_cus = 0)
 {
     long long best = -1;
     int th = H;
@@ -237,7 +242,9 @@ inline int pick_tile_rows(int H, int R, long long blocks_per_strip, long long sl
         if (t < 6 && gy > 1) break;       // tiny strips only ever win when the grid is far below one round
         if ((H + t - 1) / t != gy) continue;
         const long long nblk = blocks_per_strip * gy;
-        const long long cost = ((nblk + slots - 1) / slots) * (t + 2 * R + 6);
+        const long long full = nblk / slots, rem = nblk % slots;
+        const long long rounds100 = full * 100 + (rem == 0 ? 0 : (rem <= lone_cus ? 62 : 100));
+        const long long cost = rounds100 * (t + 2 * R + 6);
         if (best < 0 || cost < best) { best = cost; th = t; }
     }
     return th;
@@ -336,7 +343,7 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
     if (th <= 0) {
         const int bpc = has_up ? blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, true>, C::NT)
                                : blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, false>, C::NT);
-        th = pick_tile_rows(a.H, C::R + 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
+        th = pick_tile_rows(a.H, C::R + 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc, bpc == 2 ? ctx->n_cu : 0);
     }
     th = (th + 1) & ~1;                              // even strips: row parity is static in the unrolled pipeline
     {
