@@ -115,7 +115,11 @@ struct SplitCfg {
 #ifdef LK_SPLIT_QSUM
     static constexpr bool QSUM = LK_SPLIT_QSUM != 0;
 #else
-    static constexpr bool QSUM = false;              // F publishes the pair sums a + b (true) or S adds the raw pairs itself (false)
+    // F publishes the pair sums a + b (true) or S adds the raw pairs itself (false).  Up to 21 x 21 (two workgroups per CU)
+    // F is the wave that paces a workgroup and S has slack: S adds (4K/L5/w21 28.4 -> 30.2 Gpx/s).  From 23 x 23 on (one
+    // workgroup per CU, 16 LDS reads per row and field) the S waves' LDS reads are the longer pole: halving their bytes
+    // wins (8K/L5/w31: level-0 LK 2.20 -> 2.08 ms; profiles/r02_j_qsum_ab.txt).
+    static constexpr bool QSUM = WIN > 21;
 #endif
     static constexpr int UN = PF >= 4 ? PF / 2 : 2;  // unrolled F group in steps: even (LDS buffer parity) and PF rows (queue slots)
     static_assert(K == 2, "one F wave feeds 126 columns: S lanes own 2 columns (K = 4 ran one 11-wave block per CU: slower)");

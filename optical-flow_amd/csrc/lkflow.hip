@@ -479,7 +479,7 @@ int launch_split(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, i
 #ifndef LK_SPLIT_K15
 #define LK_SPLIT_K15 2
 #endif
-        SP_CASE(15, LK_SPLIT_K15) SP_CASE(21, 2)
+        SP_CASE(15, LK_SPLIT_K15) SP_CASE(21, 2) SP_CASE(31, 2)
 #else
         SP_CASE(5, 2) SP_CASE(7, 2) SP_CASE(9, 2) SP_CASE(11, 2) SP_CASE(13, 2) SP_CASE(15, 2)
         SP_CASE(17, 2) SP_CASE(19, 2) SP_CASE(21, 2) SP_CASE(23, 2) SP_CASE(25, 2) SP_CASE(27, 2) SP_CASE(29, 2) SP_CASE(31, 2)
