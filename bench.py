@@ -662,6 +662,8 @@ def main():
             if args.config == "1080p":                       # the other BASELINE shapes, in the driver's record
                 out["config_4k"] = extra_config(lkf, torch, synth, "4k", local_rank)
                 out["config_webcam"] = extra_config(lkf, torch, synth, "webcam", local_rank)
+                out["config_8k"] = extra_config(lkf, torch, synth, "8k", local_rank, steps=5)        # BASELINE config 4's shape
+                out["config_pacman"] = extra_config(lkf, torch, synth, "pacman", local_rank)         # BASELINE config 3's shape
             out["preprocess"] = preprocess_rate(ctx, torch, local_rank)
             out["video_pipeline"] = video_pipeline_rate(lkf, torch, local_rank)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
