@@ -91,7 +91,16 @@ struct SplitCfg {
     static constexpr int LAG = FW ? 2 : 0;           // pipeline steps the W role runs ahead of F
     static constexpr int PF = LK_SPLIT_PF;           // image rows in flight per F lane: a pipeline step is short, HBM latency is not
     static constexpr int NB = K;                     // B waves: 64 columns each
-    static constexpr int NF = 1;                     // one F wave: lane 0 is a halo pair (left tap of lane 1), lanes 1..63 = 126 columns
+#ifndef LK_SPLIT_NF2_MIN
+#define LK_SPLIT_NF2_MIN 99   /* smallest window whose workgroups have two F waves (99: never -- measured slower at 31x31, see below) */
+#endif
+    // F waves: lane 0 is a halo pair (left tap of lane 1), lanes 1..63 = 126 columns.  Windows that run ONE workgroup per
+    // CU anyway (ring > 128 VGPRs) have room for a ninth wave, and there the F instruction stream paces the workgroup
+    // (F publishing quad sums as well, +30 instructions per step, cost +13 %): with -DLK_SPLIT_NF2_MIN=23 two F waves march
+    // the same rows (same loads -- the second copy hits the CU's L1) and each computes the derivatives and products of ONE
+    // row of the step's pair.  Bit-identical, but nine waves put three on one SIMD = 168 VGPRs, and the 31 x 31 ring then
+    // spills 68 bytes: 8K/L5/w31 level-0 LK 2.02 -> 2.45 ms (profiles/r02_j_bigwin_knobs_ab.txt).  Off.
+    static constexpr int NF = (!FW && WIN >= LK_SPLIT_NF2_MIN) ? 2 : 1;
     static constexpr int TXC = 64 * K - 2;           // columns per block with products
     static constexpr int HL = R + (R & 1);           // halo columns on each side (even: a lane's column pair is 16-byte aligned)
     static constexpr int XO = TXC - 2 * HL;          // output columns per block
@@ -110,7 +119,7 @@ struct SplitCfg {
     static constexpr int WPE = LK_SPLIT_WPE;
 #else
     // waves per SIMD to compile for (8-wave blocks: 4 -> two blocks per CU; 10-wave blocks with the W role: 5 -> two blocks)
-    static constexpr int WPE = FW ? 5 : ((K == 2 && WIN <= 21) ? 4 : 1);
+    static constexpr int WPE = FW ? 5 : ((K == 2 && WIN <= 21) ? 4 : (NF == 2 ? 3 : 1));   // nine waves: three on one SIMD
 #endif
 #ifdef LK_SPLIT_QSUM
     static constexpr bool QSUM = LK_SPLIT_QSUM != 0;
@@ -346,7 +355,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     [[maybe_unused]] auto up_srow_w = [&](int k) { const int Hc = H >> 1; return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };
     [[maybe_unused]] auto rot_row_off = [&](int t) { return max(up_srow_w(((ye0 + 2 * t) >> 1) + 1) - c_lo, 0); };   // row W-step t rotates in
 
-    if (!FW && wv > C::NB + 5) {                     // diagnostic idle waves (LK_SPLIT_IDLE_WAVES)
+    if (!FW && wv >= C::NB + 5 + C::NF) {            // diagnostic idle waves (LK_SPLIT_IDLE_WAVES)
         for (int k = 0; k < NS; ++k) __syncthreads();
     } else if (FW && wv > C::NB + 5) {
       if constexpr (FW) {                            // (not even compiled for the unfused kernel)
@@ -487,7 +496,8 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // the one wave that feeds the block's pipeline from memory issues ahead of the seven that consume (A/B: level-0
         // launch 0.80 -> 0.77 ms; raising B instead, or both, gains nothing)
         __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_F);
-        const int m = ltid - 64 * (C::NB + 5);   // lane: block columns 2(m-1), 2(m-1)+1; lane 0 = the pair left of the block
+        const int m = ltid & 63;                 // lane: block columns 2(m-1), 2(m-1)+1; lane 0 = the pair left of the block
+        [[maybe_unused]] const int fe = wv - (C::NB + 5);   // two F waves: this one makes the products of row fe of every step
       if constexpr (FW) {
         // fused warp: the rows come from the W waves through LDS (plane (t - 1) & 1 in pipeline step t); F-step s = t - 2.
         // Steps 0 and 1 run the same code on rows nobody consumes (step 1 leaves row yy0 - 1 behind as the previous row).
@@ -630,6 +640,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             }
             const int yy = yy0 + i;
             const bool row_in = yy >= 0 && yy < H;
+            if (C::NF == 1 || fe == E) {                     // (wave-uniform; no memory instruction inside)
 #ifdef LK_SPLIT_ABL_F   /* timing-only ablation build: no derivative arithmetic */
             double fxa = ca[0], fya = ca[1], fxb = cb[0], fyb = cb[1];
             const double fta = pl[0] + cl[0], ftb = pl[1] + cl[1] + pa[0] + pb[1];
@@ -664,6 +675,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             put(std::integral_constant<int, 2>{}, fxa * fya, fxb * fyb);
             put(std::integral_constant<int, 3>{}, fxa * fta, fxb * ftb);
             put(std::integral_constant<int, 4>{}, fya * fta, fyb * ftb);
+            }
             // rotate: the only wait for the prefetch
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
