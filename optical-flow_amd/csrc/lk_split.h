@@ -92,15 +92,20 @@ struct SplitCfg {
     static constexpr int PF = LK_SPLIT_PF;           // image rows in flight per F lane: a pipeline step is short, HBM latency is not
     static constexpr int NB = K;                     // B waves: 64 columns each
 #ifndef LK_SPLIT_NF2_MIN
-#define LK_SPLIT_NF2_MIN 99   /* smallest window whose workgroups have two F waves (99: never -- measured slower at 31x31, see below) */
+#define LK_SPLIT_NF2_MIN 23   /* windows LK_SPLIT_NF2_MIN .. LK_SPLIT_NF2_MAX: two F waves per workgroup */
+#endif
+#ifndef LK_SPLIT_NF2_MAX
+#define LK_SPLIT_NF2_MAX 27
 #endif
     // F waves: lane 0 is a halo pair (left tap of lane 1), lanes 1..63 = 126 columns.  Windows that run ONE workgroup per
     // CU anyway (ring > 128 VGPRs) have room for a ninth wave, and there the F instruction stream paces the workgroup
-    // (F publishing quad sums as well, +30 instructions per step, cost +13 %): with -DLK_SPLIT_NF2_MIN=23 two F waves march
-    // the same rows (same loads -- the second copy hits the CU's L1) and each computes the derivatives and products of ONE
-    // row of the step's pair.  Bit-identical, but nine waves put three on one SIMD = 168 VGPRs, and the 31 x 31 ring then
-    // spills 68 bytes: 8K/L5/w31 level-0 LK 2.02 -> 2.45 ms (profiles/r02_j_bigwin_knobs_ab.txt).  Off.
-    static constexpr int NF = (!FW && WIN >= LK_SPLIT_NF2_MIN) ? 2 : 1;
+    // (F publishing quad sums as well, +30 instructions per step, cost +13 % at 31 x 31): two F waves march the same rows
+    // (same loads -- the second copy hits the CU's L1) and each computes the derivatives and products of ONE row of the
+    // step's pair.  Bit-identical.  Nine waves put three on one SIMD = 168 VGPRs: 23 x 23 .. 27 x 27 fit (143 .. 165) and
+    // gain 4-5 % (3840 x 2160 / L5, level-0 LK 1.00 -> 0.95 ms at 23 x 23, 1.03 -> 0.995 at 27 x 27); the 29 x 29 and
+    // 31 x 31 rings would spill (31 x 31: 68 bytes, 8K/L5/w31 level-0 LK 2.02 -> 2.45 ms) and keep one F wave
+    // (profiles/r02_j_bigwin_knobs_ab.txt).
+    static constexpr int NF = (!FW && WIN >= LK_SPLIT_NF2_MIN && WIN <= LK_SPLIT_NF2_MAX) ? 2 : 1;
     static constexpr int TXC = 64 * K - 2;           // columns per block with products
     static constexpr int HL = R + (R & 1);           // halo columns on each side (even: a lane's column pair is 16-byte aligned)
     static constexpr int XO = TXC - 2 * HL;          // output columns per block
