@@ -102,6 +102,25 @@ def usable_cores():
 # ---------------------------------------------------------------------------------------------------
 # one measured configuration (headline and the extra config objects share this)
 # ---------------------------------------------------------------------------------------------------
+PREWARM_S = float(os.environ.get("LKFLOW_BENCH_PREWARM_S", "0.3"))
+
+
+def prewarm(torch, step, seconds=None):
+    """Untimed: run `step` for a fixed wall time before the W warm-up steps.  Three 2 ms steps do not bring the part to
+    its steady state (clocks / power state after the idle data-generation phase): with --warmup 3 the timed region of
+    the headline runs 2.5-4 % slower than with --warmup 60 or 200 (profiles/r02_j_warmup_ab.txt), whatever follows.
+    The count is reported in the JSON line (`config.prewarm_steps`)."""
+    seconds = PREWARM_S if seconds is None else seconds
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        step()
+        n += 1
+        if n % 4 == 0:
+            torch.cuda.synchronize()                     # (the host must not queue seconds of work ahead of the clock)
+    torch.cuda.synchronize()
+    return n
+
+
 def make_inputs(torch, synth, name, P, rows, cols, dev, seed):
     if name in VIDEO_CONFIGS:
         frames = synth.video_torch(P + 1, rows, cols, dev, seed=seed)
@@ -150,6 +169,7 @@ def extra_config(lkf, torch, synth, name, device, steps=10, warmup=2):
     ctx = lkf.Context(device)
     ctx.reserve(rows, cols, levels, P)
     stream = torch.cuda.current_stream()
+    prewarm(torch, lambda: ctx.compute_batch(prev, nxt, levels, win, out=(U, V), stream=stream), PREWARM_S / 2)
     for _ in range(warmup):
         ctx.compute_batch(prev, nxt, levels, win, out=(U, V), stream=stream)
     torch.cuda.synchronize()
@@ -547,6 +567,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    n_prewarm = prewarm(torch, step)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -607,6 +628,7 @@ def main():
                 "pairs_per_step_per_gpu": P,
                 "parallelism": f"frame-pair sharding x{world} (no data-path collective)",
                 "launch": "hip-graph replay" if args.graph else "eager",
+                "prewarm_steps": n_prewarm,                  # untimed, before the W warm-up steps (see prewarm())
                 "chunks_in_flight": K,
             },
             "frame_pairs_per_s": round(P * world * args.steps / dt, 2),
