@@ -23,12 +23,23 @@
 #include "lk_kernels.h"
 #include "lk_march3.h"
 #include "lk_split.h"
+#include "lk_batch.h"
 #include "lk_w3x2.h"
 #include "lk_w3x2f.h"
 
-#define LKFLOW_VERSION_STR "lkflow-mi355x 0.1 (gfx950)"
+#define LKFLOW_VERSION_STR "lkflow-mi355x 0.3 (gfx950)"
 
 namespace {
+
+// A/B knobs of the tuning tools (tools/ab.sh builds a second library with -DLKFLOW_DEBUG_KNOBS and points the Python
+// binding at it).  The shipped library reads NO environment variable: every knob folds to its default at compile time.
+#ifdef LKFLOW_DEBUG_KNOBS
+inline int knob(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+constexpr int knob(const char *, int dflt) { return dflt; }
+#endif
+// "this launcher does not take the shape" (the caller falls back to the next kernel); distinct from every lkflow_status
+constexpr int LK_NOT_TAKEN = 1;
 
 using lk::CPlanes;
 using lk::Planes;
@@ -44,7 +55,7 @@ struct Level {
 }  // namespace
 
 #ifndef LKFLOW_SPLIT_FUSED_DEFAULT
-#define LKFLOW_SPLIT_FUSED_DEFAULT 0                 /* A/B builds: -DLKFLOW_SPLIT_FUSED_DEFAULT=1 */
+#define LKFLOW_SPLIT_FUSED_DEFAULT 1                 /* A/B builds: -DLKFLOW_SPLIT_FUSED_DEFAULT=1 */
 #endif
 struct lkflow_ctx {
     int device = 0;
@@ -119,7 +130,7 @@ struct ProfScope {
     lkflow_ctx *ctx; hipStream_t s; bool on; hipEvent_t a = nullptr, b = nullptr; int slot;
     ProfScope(lkflow_ctx *c, int stage, int level, hipStream_t st) : ctx(c), s(st), slot(stage * LKFLOW_MAX_LEVELS + level)
     {
-        on = (c->profile == -1 || c->profile == 1 + slot) && c->recs.size() < MAX_PROFILE_RECS;
+        on = stage >= 0 && (c->profile == -1 || c->profile == 1 + slot) && c->recs.size() < MAX_PROFILE_RECS;   // stage < 0: the caller brackets
         if (on) {
             a = ev_get(c); b = ev_get(c);
             if (!a || !b) {                                  // event creation failed: give back what exists, do not time
@@ -306,7 +317,7 @@ struct BorderFork {
     lkflow_ctx *ctx; hipStream_t s, bs;
     BorderFork(lkflow_ctx *c, hipStream_t st) : ctx(c), s(st), bs(st)
     {
-        static const int side = getenv("LKFLOW_BORDER_SIDE") ? atoi(getenv("LKFLOW_BORDER_SIDE")) : 0;
+        static const int side = knob("LKFLOW_BORDER_SIDE", 0);
         if (!side) return;
         if (!ctx->side_stream) {
             if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -337,7 +348,7 @@ template <int WIN, int K>
 int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
 {
     using C = lk::SplitCfg<WIN, K>;
-    if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return -1;   // odd / tiny levels: one-role kernel
+    if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return LK_NOT_TAKEN;   // odd / tiny levels: one-role kernel
     const int gx = (a.W + C::XO - 1) / C::XO;
     int th = ctx->tile_rows;
     if (th <= 0) {
@@ -377,7 +388,7 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
     const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
     const long long nfp = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
     if (nfp + 2 * C::NT >= 0x7fffffffLL) return LKFLOW_E_ARG;   // (the frame code indexes the pixels of one plane's frame with 32 bits)
-    static const int merged = getenv("LKFLOW_BORDER_MERGED") ? atoi(getenv("LKFLOW_BORDER_MERGED")) : 1;   // debug knob (A/B)
+    static const int merged = knob("LKFLOW_BORDER_MERGED", 1);
     const long long nbb = (nfp + C::NT - 1) / C::NT;
     if (merged && (long long)grid.x + nbb * pairs <= 0x7fffffffLL) {
         // as trailing workgroups of the main launch
@@ -401,14 +412,14 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
 }
 
 // Warp fused into the wave-specialised kernel (lk_split.h, W role): a.i1 / a.i2 are the UN-warped level images,
-// the warped planes never reach memory.  -1: shape not taken (the caller runs warp + LK).
+// the warped planes never reach memory.  LK_NOT_TAKEN: shape not taken (the caller runs warp + LK).
 template <int WIN, int K>
 int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
 {
     using C = lk::SplitCfg<WIN, K, true>;
-    if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return -1;
+    if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return LK_NOT_TAKEN;
     // the W role addresses a whole image plane with 32-bit byte offsets and one pitch for both images
-    if (a.i1.pitch != a.i2.pitch || (long long)a.H * a.i1.pitch * 8 > 0x7fffffffLL) return -1;
+    if (a.i1.pitch != a.i2.pitch || (long long)a.H * a.i1.pitch * 8 > 0x7fffffffLL) return LK_NOT_TAKEN;
     const int gx = (a.W + C::XO - 1) / C::XO;
     int th = ctx->tile_rows;
     if (th <= 0) {
@@ -452,25 +463,25 @@ int launch_splitw(lkflow_ctx *ctx, const lk::LKArgs &a, int pairs, int win, hipS
         SP_CASE(5) SP_CASE(7) SP_CASE(9) SP_CASE(11) SP_CASE(13) SP_CASE(15)
 #endif
 #undef SP_CASE
-        default: return -1;
+        default: return LK_NOT_TAKEN;
     }
 }
 
 // shapes the wave-specialised kernel takes (the rest -- odd or tiny levels -- runs the one-role kernel)
 bool split_applies(int win, int W, int H)
 {
-    static const int split = getenv("LKFLOW_SPLIT") ? atoi(getenv("LKFLOW_SPLIT")) : 1;   // debug knob (A/B): 0 = one-role kernel
+    static const int split = knob("LKFLOW_SPLIT", 1);            // A/B: 0 = one-role kernel
     const int R = win / 2;
     return split && win >= 5 && win <= LKFLOW_MAX_WIN && !(W & 1) && !(H & 1) && W >= 2 && H > R + LK_SPLIT_PF + 1;
 }
 
 bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H)
 {
-    static const int env = getenv("LKFLOW_SPLIT_FUSED") ? atoi(getenv("LKFLOW_SPLIT_FUSED")) : -1;   // debug knob (A/B): overrides the option
+    static const int env = knob("LKFLOW_SPLIT_FUSED", -1);       // A/B: overrides the option
     return (env >= 0 ? env : ctx->fuse_warp) && ctx->impl == 0 && win <= LKFLOW_SPLIT_FUSED_MAX_WIN && split_applies(win, W, H);
 }
 
-// -1: this window has no wave-specialised instantiation
+// LK_NOT_TAKEN: this window has no wave-specialised instantiation
 int launch_split(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, int win, hipStream_t s)
 {
     switch (win) {
@@ -488,7 +499,69 @@ int launch_split(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, i
         SP_CASE(17, 2) SP_CASE(19, 2) SP_CASE(21, 2) SP_CASE(23, 2) SP_CASE(25, 2) SP_CASE(27, 2) SP_CASE(29, 2) SP_CASE(31, 2)
 #endif
 #undef SP_CASE
-        default: return -1;
+        default: return LK_NOT_TAKEN;
+    }
+}
+
+// Batch-synchronous kernel (lk_batch.h): 8 identical waves, 8 marched rows per phase pair; fw: a.i1 / a.i2 are the
+// UN-warped level images and the warp of the level runs inside the kernel.  LK_NOT_TAKEN: shape not taken.
+template <int WIN>
+int launch_batch_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, bool fw, int pairs, hipStream_t s, int stage, int level)
+{
+    using C = lk::BatchCfg<WIN>;
+    if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + 3) return LK_NOT_TAKEN;
+    if (a.i1.pitch != a.i2.pitch) return LK_NOT_TAKEN;           // (the kernel indexes both images with one pitch)
+    if (fw && !has_up) return LKFLOW_E_ARG;
+    const int gx = (a.W + C::XO - 1) / C::XO;
+    int th = ctx->tile_rows;
+    if (th <= 0) {
+        const int bpc = fw ? blocks_per_cu(ctx, lk::lk_batch_kernel<WIN, true, true>, C::NT)
+                           : (has_up ? blocks_per_cu(ctx, lk::lk_batch_kernel<WIN, true, false>, C::NT)
+                                     : blocks_per_cu(ctx, lk::lk_batch_kernel<WIN, false, false>, C::NT));
+        // a strip marches th + R + APR rows rounded up to whole batches, plus one more phase A
+        th = pick_tile_rows(a.H, (C::R + C::APR + 12) / 2, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
+    }
+    th = (th + 7) & ~7;                              // whole batches: the chunk position of a batch row is static
+    a.th = th;
+    a.gx = gx; a.gy = (a.H + th - 1) / th;
+    if ((long long)a.gx * a.gy * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
+    dim3 grid((unsigned)(a.gx * a.gy * pairs));      // 1-D: the kernel orders the tiles per XCD
+    // the frame of clipped-window pixels (SerialPyr.cpp:94-95) and the outermost ring: trailing workgroups
+    const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
+    const long long nfp = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
+    if (nfp + 2 * C::NT >= 0x7fffffffLL) return LKFLOW_E_ARG;
+    const long long nbb = (nfp + C::NT - 1) / C::NT;
+    if ((long long)grid.x + nbb * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
+    a.nmain = grid.x; a.nbb = (unsigned)nbb;
+    grid.x += (unsigned)(nbb * pairs);
+    ProfScope ps(ctx, stage, level, s);              // (opened only once the shape is taken)
+    if (fw) hipLaunchKernelGGL((lk::lk_batch_kernel<WIN, true, true>), grid, dim3(C::NT), 0, s, a);
+    else if (has_up) hipLaunchKernelGGL((lk::lk_batch_kernel<WIN, true, false>), grid, dim3(C::NT), 0, s, a);
+    else hipLaunchKernelGGL((lk::lk_batch_kernel<WIN, false, false>), grid, dim3(C::NT), 0, s, a);
+    return LKFLOW_OK;
+}
+
+// windows the batch-synchronous kernel is built for (<= 128 VGPRs with the WIN x 4 register ring)
+bool batch_applies(const lkflow_ctx *ctx, int win, int W, int H)
+{
+#ifndef LKFLOW_BATCH_DEFAULT
+#define LKFLOW_BATCH_DEFAULT 0                       /* until it beats warp + lk_split on the box */
+#endif
+    static const int on = knob("LKFLOW_BATCH", LKFLOW_BATCH_DEFAULT);   // A/B
+    return on && ctx->impl == 0 && win >= 5 && win <= 15 && !(W & 1) && !(H & 1) && W >= 2 && H > win / 2 + 3;
+}
+
+int launch_batch(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, bool fw, int pairs, int win, hipStream_t s, int stage, int level)
+{
+    switch (win) {
+#define BT_CASE(WN) case WN: return launch_batch_win<WN>(ctx, a, has_up, fw, pairs, s, stage, level);
+#ifdef LKFLOW_FAST_BUILD
+        BT_CASE(15)
+#else
+        BT_CASE(5) BT_CASE(7) BT_CASE(9) BT_CASE(11) BT_CASE(13) BT_CASE(15)
+#endif
+#undef BT_CASE
+        default: return LK_NOT_TAKEN;
     }
 }
 
@@ -515,7 +588,7 @@ int launch_w3x2(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream
 // warp + LK fused for 3 x 3 windows (lk_w3x2f.h): a.i1 / a.i2 are the UN-warped level images
 bool fused_w3_applies(const lkflow_ctx *ctx, int win, int W, int H)
 {
-    static const bool off = getenv("LKFLOW_NO_W3_FUSED") != nullptr || getenv("LKFLOW_NO_W3X2") != nullptr;   // debug knobs (A/B)
+    static const bool off = knob("LKFLOW_NO_W3_FUSED", 0) || knob("LKFLOW_NO_W3X2", 0);
     return !off && ctx->impl == 0 && win == 3 && W >= 2 && !(W & 1) && !(H & 1);
 }
 int launch_w3x2f(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
@@ -576,16 +649,19 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
         const long long c128 = (long long)((a.W + (128 - 2 * R) - 1) / (128 - 2 * R)) * 128;
         const long long c256 = (long long)((a.W + (256 - 2 * R) - 1) / (256 - 2 * R)) * 256;
         bool use128 = win <= 15 && c128 * 100 <= c256 * 108;
-        { static const int e = getenv("LKFLOW_LK_TX") ? atoi(getenv("LKFLOW_LK_TX")) : 0;   // debug knob
+        { static const int e = knob("LKFLOW_LK_TX", 0);
           if (e == 128) use128 = true; else if (e == 256) use128 = false; }
         int rc;
-        static const bool no_w3 = getenv("LKFLOW_NO_W3_DPP") != nullptr;          // debug knob (A/B)
-        static const bool no_x2 = getenv("LKFLOW_NO_W3X2") != nullptr;            // debug knob (A/B)
+        static const bool no_w3 = knob("LKFLOW_NO_W3_DPP", 0) != 0;
+        static const bool no_x2 = knob("LKFLOW_NO_W3X2", 0) != 0;
         if (win == 3 && !no_x2 && a.W >= 2 && !(a.W & 1)) rc = launch_w3x2(ctx, a, has_up, pairs, s);   // 2 columns per lane
         else if (win == 3 && !no_w3) rc = launch_lk3_win<3, 64>(ctx, a, has_up, pairs, s);   // barrier-free DPP kernel
         else {
-            rc = split_applies(win, a.W, a.H) ? launch_split(ctx, a, has_up, pairs, win, s) : -1;
-            if (rc == -1)
+            static const int batch_lk = knob("LKFLOW_BATCH_LK", 1);   // A/B: 0 = wave-specialised kernel for plain (unfused) LK levels
+            rc = (batch_lk && batch_applies(ctx, win, a.W, a.H)) ? launch_batch(ctx, a, has_up, false, pairs, win, s, -1, 0) : LK_NOT_TAKEN;
+            if (rc == LK_NOT_TAKEN)
+                rc = split_applies(win, a.W, a.H) ? launch_split(ctx, a, has_up, pairs, win, s) : LK_NOT_TAKEN;
+            if (rc == LK_NOT_TAKEN)
                 rc = use128 ? launch_lk3<128>(ctx, a, has_up, pairs, win, s) : launch_lk3<256>(ctx, a, has_up, pairs, win, s);
         }
 #endif
@@ -605,7 +681,7 @@ int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int p
 #define LK_PD_TH 16
 #endif
     a.th = LK_PD_TH;
-    { static const int e = getenv("LKFLOW_PD_TH") ? atoi(getenv("LKFLOW_PD_TH")) : 0; if (e > 0) a.th = e; }
+    { static const int e = knob("LKFLOW_PD_TH", 0); if (e > 0) a.th = e; }
     a.gx = (a.Wd + 4 * lk::PD_WCOLS - 1) / (4 * lk::PD_WCOLS); a.gy = (a.Hd + a.th - 1) / a.th;
     if ((long long)(2 * a.th + 6) * 8 * std::max(src.pitch, dst.pitch) > 0x7fffffffLL) return LKFLOW_E_ARG;   // strip-relative 32-bit offsets
     const long long n = (long long)a.gx * a.gy * planes;
@@ -625,7 +701,7 @@ int launch_warp(lkflow_ctx *ctx, CPlanes i1, CPlanes i2, int H, int W, CPlanes c
 #define LK_WARP_TH 16
 #endif
     a.th = LK_WARP_TH;                           // even; two rows per iteration
-    { static const int e = getenv("LKFLOW_WARP_TH") ? atoi(getenv("LKFLOW_WARP_TH")) : 0; if (e > 0) a.th = e & ~1; }
+    { static const int e = knob("LKFLOW_WARP_TH", 0); if (e > 0) a.th = e & ~1; }
     a.gx = (W + 255) / 256; a.gy = (H + a.th - 1) / a.th;
     if ((long long)(a.th + 2) * 8 * std::max(std::max(o1.pitch, o2.pitch), std::max(cu.pitch, cv.pitch)) > 0x7fffffffLL)
         return LKFLOW_E_ARG;                      // strip-relative 32-bit byte offsets
@@ -674,8 +750,8 @@ int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok,
     int rc = check_win(win);
     if (rc) return rc;
     const char *up = has_up ? "true" : "false";
-    static const bool no_fused = getenv("LKFLOW_NO_W3_FUSED") != nullptr || getenv("LKFLOW_NO_W3X2") != nullptr;
-    static const bool no_x2 = getenv("LKFLOW_NO_W3X2") != nullptr, no_w3 = getenv("LKFLOW_NO_W3_DPP") != nullptr;
+    static const bool no_fused = knob("LKFLOW_NO_W3_FUSED", 0) || knob("LKFLOW_NO_W3X2", 0);
+    static const bool no_x2 = knob("LKFLOW_NO_W3X2", 0) != 0, no_w3 = knob("LKFLOW_NO_W3_DPP", 0) != 0;
     if (win == 3 && has_up && fused_ok && !no_fused && cols >= 2 && !(cols & 1) && !(rows & 1)) snprintf(buf, n, "lk::lk_w3x2f_kernel");
     else if (win == 3 && !no_x2 && cols >= 2 && !(cols & 1)) snprintf(buf, n, "lk::lk_w3x2_kernel<%s>", up);
     else if (win == 3 && !no_w3) snprintf(buf, n, "lk::lk_march3_kernel<3, 64, %s>", up);
@@ -904,6 +980,15 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
             if ((rc = launch_w3x2f(ctx, a, P, s))) return rc;
             continue;
         }
+        if (has_up && ctx->fuse_warp && batch_applies(ctx, win, lv[l].W, lv[l].H) && !((flags & LKFLOW_MUTATE_INPUTS) && l == 0)) {
+            // windows 5..15: warp and LK in one batch-synchronous kernel (lk_batch.h), the warped images never reach memory
+            lk::LKArgs f = a;
+            f.i1 = pyr(l, 0); f.i2 = pyr(l, 1);
+            f.cu = as_c(flow_w(l + 1, 0)); f.cv = as_c(flow_w(l + 1, 1));
+            rc = launch_batch(ctx, f, true, true, P, win, s, LKFLOW_STAGE_LK, l);
+            if (rc == LKFLOW_OK) { HIP_TRY(ctx, hipGetLastError()); continue; }
+            if (rc != LK_NOT_TAKEN) return rc;                   // not taken: warp + LK below
+        } else
         if (has_up && fused_split_applies(ctx, win, lv[l].W, lv[l].H) && !((flags & LKFLOW_MUTATE_INPUTS) && l == 0)) {
             // windows 5..15: warp and LK in one kernel (lk_split.h, W role), the warped images never reach memory
             lk::LKArgs f = a;
@@ -912,7 +997,7 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
             ProfScope ps(ctx, LKFLOW_STAGE_LK, l, s);
             rc = launch_splitw(ctx, f, P, win, s);
             if (rc == LKFLOW_OK) continue;
-            if (rc != -1) return rc;                             // -1: shape not taken, warp + LK below
+            if (rc != LK_NOT_TAKEN) return rc;                   // not taken: warp + LK below
         }
         if (has_up) {
             CPlanes cu = as_c(flow_w(l + 1, 0)), cv = as_c(flow_w(l + 1, 1));
