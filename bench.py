@@ -28,7 +28,7 @@ CONFIGS = {
     # name: (cols, rows, levels, win, default pairs/step/GPU)   -- BASELINE.json configs[1..4]
     "1080p": (1920, 1080, 3, 15, 32),
     "4k": (3840, 2160, 5, 21, 8),
-    "8k": (7680, 4320, 5, 31, 4),
+    "8k": (7680, 4320, 5, 31, 32),     # 256-frame batch over 8 GPUs = 33 frames / 32 pairs per rank (north_star)
     "pacman": (240, 160, 3, 15, 244),
     # the reference's own shipped loop: 1080x1080 CV_64F, getMaxLayer = 4 levels, 3x3 (ParallelVideoPyr.cpp:782,831)
     "webcam": (1080, 1080, 4, 3, 48),
@@ -63,19 +63,48 @@ def lk0_bytes_per_pair(cols, rows, levels, fused=False):
     return 8 * (4 * n[0] + 2 * n[1])
 
 
-def measured_traffic(kernel_name, cols, rows, pairs):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
-    (profiles/pmc_traffic.json, written by tools/prof_pmc.sh for THIS workload), or None."""
+def csrc_digest():
+    """sha256 over the kernel sources (optical-flow_amd/csrc/*, include/lkflow.h), names and contents, sorted: the code a
+    PMC pass or a kernel trace was measured on.  tools/pmc_summary.py stamps it into profiles/pmc_traffic.json."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(ROOT, "optical-flow_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "optical-flow_amd", "csrc")))
+    files.append(os.path.join(ROOT, "include", "lkflow.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _profile_record():
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
-            d = json.load(fh)
+            return json.load(fh)
     except (OSError, ValueError):
-        return None
-    if d.get("_workload") != f"{cols}x{rows}x{pairs}":
+        return {}
+
+
+def measured_traffic(kernel_name, cols, rows, pairs):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/pmc_traffic.json,
+    written by tools/prof_pmc.sh for THIS workload and THIS code: the file carries the digest of the kernel sources it was
+    measured on), or None -- a stale file after a kernel change must not be reported as a measurement."""
+    d = _profile_record()
+    if d.get("_workload") != f"{cols}x{rows}x{pairs}" or d.get("_csrc_sha") != csrc_digest():
         return None
     v = d.get(kernel_name)
     return int(v["hbm_read_bytes"] + v["hbm_write_bytes"]) if isinstance(v, dict) else None
+
+
+def rocprof_avg_launch_ms(kernel_name, cols, rows, pairs):
+    """Mean duration of the dominant kernel's level-0 dispatches in the committed rocprofv3 --kernel-trace of the same
+    command (stamped into profiles/pmc_traffic.json by tools/prof_round.sh), or None if the code has changed since."""
+    d = _profile_record()
+    if d.get("_workload") != f"{cols}x{rows}x{pairs}" or d.get("_csrc_sha") != csrc_digest():
+        return None
+    v = d.get(kernel_name)
+    return v.get("rocprof_avg_launch_ms") if isinstance(v, dict) else None
 
 
 def usable_cores():
@@ -147,7 +176,8 @@ def roofline_objects(lkf, name, cols, rows, levels, win, P, pairs_per_launch, lk
         # FETCH_SIZE correction applied; committed under profiles/), null if not collected for this workload
         "traffic": measured_traffic(kname, cols, rows, pairs_per_launch),
         "algorithmic_bytes_per_launch": lk0_bytes,
-        "avg_launch_ms": round(lk0_avg_s * 1e3, 4),
+        "avg_launch_ms": round(lk0_avg_s * 1e3, 4),           # HIP events on the launch stream, this run
+        "rocprof_avg_launch_ms": rocprof_avg_launch_ms(kname, cols, rows, pairs_per_launch),   # committed trace, same code
         "launches_timed": lk0_n,
         "pairs_per_launch": pairs_per_launch,
     }
@@ -629,6 +659,7 @@ def main():
                 "parallelism": f"frame-pair sharding x{world} (no data-path collective)",
                 "launch": "hip-graph replay" if args.graph else "eager",
                 "prewarm_steps": n_prewarm,                  # untimed, before the W warm-up steps (see prewarm())
+                "prewarm_s": PREWARM_S,
                 "chunks_in_flight": K,
             },
             "frame_pairs_per_s": round(P * world * args.steps / dt, 2),
@@ -651,7 +682,7 @@ def main():
             if rank == 0:
                 out["stream_sharding"] = {"error": "deadline: a rank did not finish the stream extra in time"}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)                                  # a stuck rank is a failure: spawn_ranks / the launcher sees it
         wd = threading.Timer(float(os.environ.get("LKFLOW_BENCH_STREAM_EXTRA_DEADLINE_S", "150")), give_up)
         wd.daemon = True
         wd.start()

@@ -81,11 +81,17 @@ int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int 
                                   points move data by asynchronous DMA instead of the pageable path.  ONLY for buffers that
                                   outlive the context or are re-used call after call (a video loop's Mats): a registered
                                   buffer must not be freed while the option is on. */
-#define LKFLOW_OPT_FUSE_WARP 5 /* 0 (default) / 1: windows 5..15 on even levels: the warp runs INSIDE the wave-specialised LK
-                                  kernel (two extra "W" waves per block produce the warped rows straight into LDS), so the
-                                  warped planes never reach memory.  Bit-identical results; measured SLOWER than warp + LK
-                                  on MI355X (10-wave blocks do not pair up on a CU: DESIGN.md section 4), hence opt-in.
-                                  Ignored with LKFLOW_MUTATE_INPUTS at level 0 (the caller wants the warped images). */
+#define LKFLOW_OPT_FUSE_WARP 5 /* 0 (default) / 1: windows 5..15 on even levels: the warp of a level runs INSIDE its LK kernel, so
+                                  the warped planes never reach memory -- in the batch-synchronous kernel if LKFLOW_OPT_LK_BATCH is
+                                  on (results within rounding of the default path), else in the wave-specialised kernel with two
+                                  extra "W" waves (bit-identical).  Both measured SLOWER than warp + LK on MI355X (DESIGN.md
+                                  section 4), hence opt-in.  Ignored with LKFLOW_MUTATE_INPUTS at level 0 (the caller wants
+                                  the warped images). */
+#define LKFLOW_OPT_LK_BATCH 6  /* 0 (default) / 1: windows 5..15 on even levels run the batch-synchronous LK kernel (lk_batch.h:
+                                  8-wave workgroups, 8 rows per barrier pair, 5 window-sum waves next to 3 producer waves)
+                                  instead of the wave-specialised one.  Same expressions; the vertical window sums are
+                                  associated in chunks of win + 1 instead of win rows (agreement ~1e-15 relative).  Experimental:
+                                  measured slower (round-3 record in DESIGN.md). */
 int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value);
 
 /* Stage ids of the kernels the pyramid driver launches (level = pyramid level the launch works at;
@@ -125,6 +131,11 @@ int lkflow_compute_u8(lkflow_ctx *ctx, const unsigned char *prev, const unsigned
  * One pair per context may be in flight (a second enqueue first waits for the first); use two contexts to overlap
  * the transfers of one pair with the kernels of another.  With pageable host memory the runtime's copies are
  * staged and partly synchronous; with LKFLOW_OPT_PIN_HOST (or hipHostMalloc'ed buffers) they are true async DMA.
+ * The pair in flight works in the context's workspace: a device-batch call (lkflow_compute_batch_f64_dev) on the same
+ * context and another stream first waits for it (as lkflow_lk_f64 does).  If an enqueue fails half way, the stream is
+ * drained before the call returns, so the caller may free its buffers on any error.  LKFLOW_OPT_PIN_HOST registrations
+ * belong to the context that made them: switch the option off (or destroy that context) only while every context that
+ * uses the same host buffers is idle.
  */
 int lkflow_enqueue_pair_f64(lkflow_ctx *ctx, double *prev, double *next, int rows, int cols, size_t step_bytes,
                             double *U, double *V, size_t uv_step_bytes, int pyr_levels, int win, unsigned flags);
@@ -142,7 +153,9 @@ int lkflow_lk_f64(lkflow_ctx *ctx, const double *img1, const double *img2, int r
  *        writes U + p*uv_pair_stride_bytes , V + p*uv_pair_stride_bytes.
  * A video of F frames with frame stride S is F-1 pairs with prev = frames, next = frames + S,
  * both pair strides = S.  All pointers are DEVICE pointers on the context's GPU.  Work is
- * enqueued on `stream` (a hipStream_t, NULL = default stream); the call does not synchronise.
+ * enqueued on `stream` (a hipStream_t, NULL = default stream); the call does not synchronise and, after
+ * lkflow_ctx_reserve() for the shape, makes no allocation: it may be captured into a HIP graph and replayed
+ * (tests/test_gpu_round3.py::test_graph_capture_after_reserve_replays_bitwise).
  */
 int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next,
                                  size_t prev_pair_stride_bytes, size_t next_pair_stride_bytes,
@@ -155,6 +168,16 @@ int lkflow_lk_batch_f64_dev(lkflow_ctx *ctx, const double *img1, const double *i
                             size_t img1_pair_stride_bytes, size_t img2_pair_stride_bytes,
                             int n_pairs, int rows, int cols, size_t step_bytes, double *U, double *V,
                             size_t uv_pair_stride_bytes, size_t uv_step_bytes, int win, void *stream);
+
+/* The same with the accumulate step of the pyramid loop (ParallelVideoPyr.cpp:634-637): U = LK(img1, img2) + pyrUp(cu),
+ * V = LK(..) + pyrUp(cv) for a coarse flow (cu, cv) of (rows/2) x (cols/2); rows and cols even.  What every level below
+ * the coarsest runs after its warp -- exposed so that the "+= pyrUp" path of the LK kernels can be parity-tested in
+ * isolation (non-finite coarse flow included). */
+int lkflow_lk_up_batch_f64_dev(lkflow_ctx *ctx, const double *img1, const double *img2,
+                               size_t img1_pair_stride_bytes, size_t img2_pair_stride_bytes,
+                               int n_pairs, int rows, int cols, size_t step_bytes, const double *cu, const double *cv,
+                               size_t c_pair_stride_bytes, size_t c_step_bytes, double *U, double *V,
+                               size_t uv_pair_stride_bytes, size_t uv_step_bytes, int win, void *stream);
 
 /* ---- stage entry points (device pointers, n_planes contiguous-or-strided planes) ------------
  * Exposed so that every kernel can be parity-tested against the oracle in isolation. */

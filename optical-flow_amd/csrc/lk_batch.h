@@ -1,36 +1,33 @@
 // lk_batch.h -- single-level dense LK (a3-a8) with the level's warp (a9-a12) FUSED IN, row-marching, BATCH-synchronous:
-// a workgroup of 8 identical waves marches a block of 126 columns down a row strip EIGHT rows at a time, and every
-// wave does every kind of work (ParallelVideoPyr.cpp:646-703 warp, :44-84 derivatives, :114-191 window sums,
-// :470-520 solve, :634-637 accumulate).
+// a workgroup of 8 waves marches a block of 126 columns down a row strip EIGHT rows at a time
+// (ParallelVideoPyr.cpp:646-703 warp, :44-84 derivatives, :114-191 window sums, :470-520 solve, :634-637 accumulate).
 //
 // Why (round 3): the wave-specialised kernel (lk_split.h) runs its three roles in lock-step, one workgroup barrier
 // per two rows, with one "F" wave feeding seven; two thirds of its time is that cadence, and a fourth role (the warp)
-// does not fit a CU twice.  Here a batch of 8 marched rows goes through two phases per workgroup:
+// does not fit a CU twice.  Here the synchronisation is per batch of 8 marched rows, two barriers per batch:
 //
-//   phase A, all 8 waves, wave w <-> row w of the batch, one column per lane, two half-rows one after the other:
-//     W part  the warped pixel pair of the row (FW: cv::pyrUp of the coarse flow at the pixel, float map, 1/32-pixel
-//             fixed-point bilinear remap of both UN-warped level images -- warp_kernel's arithmetic; !FW: a plain
-//             load) -> s = I1w + I2w and d = I2w - I1w -> LDS rows (the warped planes never reach memory);
-//     B part  the five window sums of one row of the PREVIOUS batch come back from LDS -> 2 x 2 solve with true fp64
-//             divisions, /0 -> 0, "+= pyrUp(coarse flow)", streaming store of u, v;
-//   phase S, waves 0..4, one FIELD each (fx^2, fy^2, fx fy, fx ft, fy ft), two adjacent columns per lane, the 8 rows
-//     of the batch one after the other: the two derivatives of the field from the (s, d) rows (left tap by a DPP wave
-//     shift, previous row's half in registers) -> product -> horizontal window: the lane's pair, its sum and the
-//     neighbours' through a wave-PRIVATE LDS row (no barrier: a wave's LDS instructions execute in order) ->
-//     vertical window: van Herk / Gil-Werman prefix + suffix ring in registers -> the row's two window sums -> LDS.
+//   phase X(n)   waves 0..4 ("S", one FIELD each: fx^2, fy^2, fx fy, fx ft, fy ft; two adjacent columns per lane) take
+//                the 8 rows of batch n, two rows per LDS round trip: the two derivatives of the field in the
+//                reference's own expression order from the (warped) image rows in LDS (left tap by a DPP wave shift,
+//                previous row in registers) -> product -> horizontal window: the lane's pair, its sum and the
+//                neighbours' through a wave-PRIVATE LDS row (no barrier: a wave's LDS instructions execute in order)
+//                -> vertical window: van Herk / Gil-Werman prefix + suffix ring in registers -> window sums -> LDS;
+//                MEANWHILE waves 5..7 ("W", one column per lane, units of a row pair x 64 columns) make the rows of
+//                batch n + 1 into the other half of a double-buffered LDS row store: FW: cv::pyrUp of the coarse flow
+//                at the pixel (parked in U, V for phase B), float map, 1/32-pixel fixed-point bilinear remap of both
+//                UN-warped level images (warp_kernel's arithmetic; the warped planes never reach memory); !FW: plain
+//                loads (+ the parked pyrUp if there is a coarser level).  All of W's memory latency hides behind S.
+//   phase B(n)   all 8 waves, one unit each: the five window sums of a row pair come back from LDS -> 2 x 2 solve with
+//                true fp64 divisions, /0 -> 0, "+= pyrUp(coarse flow)" (parked by W), streaming store of u, v.
 //
-// Two workgroup barriers per EIGHT rows (lk_split.h: four), every wave with the same instruction stream in phase A,
-// five of eight busy in phase S; two workgroups per CU (<= 128 VGPRs, 66 KB LDS) run in different phases.
+// Two workgroup barriers per EIGHT rows (lk_split.h: four); two workgroups per CU (<= 128 VGPRs, 76 KB LDS).
 //
-// Arithmetic.  Window sums use additions only (flat regions give exactly 0 like the reference).  The derivatives are
-// evaluated separably on s = I1 + I2 and d = I2 - I1:
-//     fx = (s(y,x) - s(y,x-1)) + (s(y-1,x) - s(y-1,x-1))        [filter2D Kx on I1 + filter2D Kx on I2, :44-56]
-//     fy = (s(y,x-1) + s(y,x)) - (s(y-1,x-1) + s(y-1,x))        [:58-70]
-//     ft = (d(y,x-1) + d(y,x)) + (d(y-1,x-1) + d(y-1,x))        [:72-84]
-// i.e. the reference's eight-term sums re-associated (each S wave needs its derivatives itself, and the separable form
-// costs 6 instead of 14 additions per derivative): results differ from lk_split.h / the oracle in the last bits of the
-// derivatives (a few 1e-16 of the pixel range), far inside the reference's own 1e-6 bar (ParallelBasicPyr.cpp:787);
-// identical frames still give ft == 0 exactly and flat regions fx == fy == 0 exactly.
+// Arithmetic: lk_device.h's expressions -- the 2 x 2 filter2D responses in OpenCV's tap order (an S wave evaluates the
+// one or two derivatives of ITS field: ((-p00 + c1 p01) + c2 p10) + c3 p11 with c = +-1.0 inside FMAs, which rounds
+// exactly where the reference's additions and subtractions round; f2d_pos(b) = -f2d_neg(b) exactly) -- then window
+// sums with additions only (flat regions give exactly 0 like the reference).  This matters: where a window holds nothing
+// but the rounding residue of the reference's own derivative order, that residue IS the reference's flow
+// (tests/test_gpu_parity.py::test_random_small_shapes_against_oracle, flat half-images).
 // The vertical ring uses chunks of L = WIN + 1 rows anchored to ABSOLUTE image rows (window = suffix of the previous
 // chunk + prefix of the current one; the two windows that lie inside one chunk are prefix[WIN-1] and suffix[1]), so
 // that a result does not depend on the strip height the launcher picks (sharded == unsharded bit for bit) and the
@@ -38,7 +35,7 @@
 //
 // The frame of width R just inside the image (clipped windows m(y,x) * WIN^2, SerialPyr.cpp:94-95, and the outermost
 // ring) is written by lk_border_pixel (lk_split.h) in trailing workgroups of the same launch.
-// Host-checked: W and H even, strip height a multiple of 8.
+// Host-checked: W and H even, strip height a multiple of 8, both images one pitch.
 #pragma once
 #include "lk_split.h"
 
@@ -80,9 +77,8 @@ __global__ __launch_bounds__(512, 4) void lk_batch_kernel(LKArgs a)
         lk_border_pixel<HAS_UP, FW>(a, WIN, (bb % a.nbb) * (unsigned)C::NT + threadIdx.x, (int)(bb / a.nbb));
         return;
     }
-    __shared__ __attribute__((aligned(16))) double s_im[8][2][128];      // [batch row][image][block column + 2]: the (warped) rows
-    __shared__ __attribute__((aligned(16))) double s_prev[2][2][128];    // [batch parity][image]: row 7 of batch n, the row above batch n + 1
-    __shared__ __attribute__((aligned(16))) double s_sums[8][5][128];    // [batch row][field][block column + 2]
+    __shared__ __attribute__((aligned(16))) double s_im[2][8][2][128];   // [batch parity][batch row][image][block column + 2]
+    __shared__ __attribute__((aligned(16))) double s_sums[8][5][XO];     // [batch row][field][output column of the workgroup]
     __shared__ double s_pa[5][C::NCH], s_pb[5][C::NCH], s_pq[5][C::NCH]; // wave-private rows: products a, b of every pair, a + b
 
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -97,7 +93,7 @@ __global__ __launch_bounds__(512, 4) void lk_batch_kernel(LKArgs a)
     const int ym0 = y0 - C::APR;                       // image row of marched row 0 (multiple of 8)
     const int x0 = bx * XO - HL;                       // image column of block column 0 (even); LDS column c = block column + 2
     const int nmr = y1 - 1 + R - ym0 + 1;              // marched rows: image rows ym0 .. y1-1+R
-    const int NBS = (nmr + 7) >> 3;                    // S batches
+    const int NBS = (nmr + 7) >> 3;                    // batches
     const int ylast = min(y1 - 1 + R, H - 1);          // last image row whose products an output needs
     const int yo_lo = max(y0, R), yo_hi = min(y1, H - R);   // output rows this workgroup stores (the frame is lk_border_pixel's)
 
@@ -107,14 +103,19 @@ __global__ __launch_bounds__(512, 4) void lk_batch_kernel(LKArgs a)
     [[maybe_unused]] const int Hc = H >> 1, Wc = W >> 1;
     double *Uo = a.u.at(pair), *Vo = a.v.at(pair);
 
-    // phase A geometry: wave wv <-> rows (2k, 2k+1) of the batch, k = wv >> 1, columns 64 (wv & 1) + lane
-    const int ak = wv >> 1;
-    const int ac = 64 * (wv & 1) + lane;               // LDS column
-    const int ax = x0 - 2 + ac;                        // image column
-    const bool a_out = ac >= HL + 2 && ac < HL + 2 + XO && ax >= R && ax < W - R;   // an output column of this workgroup, not in the frame
-    // column -1 is filter2D's reflect-101 tap of column 0 = column 1; other columns outside the image only feed products
-    // that S zeroes (any in-image column will do)
-    const int axw = min(ax < 0 ? -ax : ax, W - 1);
+    // a UNIT = the row pair (2k, 2k+1) of a batch x 64 columns, one column per lane: unit u = 2 k + half
+    struct Unit { int k, c, x, xw; bool out; };
+    auto unit = [&](int u) __attribute__((always_inline)) {
+        Unit t;
+        t.k = u >> 1;
+        t.c = 64 * (u & 1) + lane;                     // LDS column
+        t.x = x0 - 2 + t.c;                            // image column
+        t.out = t.c >= HL + 2 && t.c < HL + 2 + XO && t.x >= R && t.x < W - R;   // an output column of this workgroup, not in the frame
+        // column -1 is filter2D's reflect-101 tap of column 0 = column 1; other columns outside the image only feed
+        // products that S zeroes (any in-image column will do)
+        t.xw = min(t.x < 0 ? -t.x : t.x, W - 1);
+        return t;
+    };
 
     // cv::pyrUp of the coarse flow at the row pair (2i, 2i+1), column x, straight-line (make_upsel1 / pyrup_h1v: pyrup_at()'s
     // roundings): [0] the even row, [1] the odd row
@@ -136,103 +137,127 @@ __global__ __launch_bounds__(512, 4) void lk_batch_kernel(LKArgs a)
         uu[1] = ((hu[1] + hu[2]) * 4) * (1.0 / 64);       vv[1] = ((hv[1] + hv[2]) * 4) * (1.0 / 64);
     };
 
-    // ---- phase A, W part: the wave's row pair of batch n -> LDS ------------------------------------------------------
-    auto wpart = [&](int n) __attribute__((always_inline)) {
-        const int ye = ym0 + 8 * n + 2 * ak;           // even image row of the pair (ym0 is even)
+    // ---- W: one unit of batch n -> LDS rows -------------------------------------------------------------------------
+    auto wunit = [&](int n, int u) __attribute__((always_inline)) {
+        const Unit t = unit(u);
+        const int ye = ym0 + 8 * n + 2 * t.k;          // even image row of the pair (ym0 is even)
         if (ye + 1 < -1 || ye > ylast) return;         // (wave-uniform) rows no output needs: S zeroes their products
         // row -1 is filter2D's reflect-101 tap of row 0 = row 1 (rows -2 and below, H and beyond: any in-image row will do)
         const int yw0 = min(ye < 0 ? 1 : ye, H - 1), yw1 = min(ye + 1 < 0 ? 1 : ye + 1, H - 1);
         double w1[2], w2[2];
-        if constexpr (FW) {
-            double uu[2], vv[2];
-            upflow2(yw0 >> 1, axw, uu, vv);
+        [[maybe_unused]] double uu[2], vv[2];
+        if constexpr (HAS_UP) {
+            upflow2(yw0 >> 1, t.xw, uu, vv);
             if (ye < 0) { uu[0] = uu[1]; vv[0] = vv[1]; }   // (wave-uniform) the pair (-2, -1) -> rows (1, 1): the odd row of coarse pair 0
+            // the up-sampled flow of an output pixel is parked in U, V: phase B adds it to the solve two batches on
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (t.out && ye + e >= yo_lo && ye + e < yo_hi) {
+                    Uo[(long long)(ye + e) * a.u.pitch + t.x] = uu[e];
+                    Vo[(long long)(ye + e) * a.v.pitch + t.x] = vv[e];
+                }
+        }
+        if constexpr (FW) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int yw = e ? yw1 : yw0;
                 const float hx = (float)uu[e] / 2, hy = (float)vv[e] / 2;   // map build (ParallelVideoPyr.cpp:674-678), float32
-                w1[e] = remap_bilinear(I1, ip, H, W, (float)axw + hx, (float)yw + hy);
-                w2[e] = remap_bilinear(I2, ip, H, W, (float)axw - hx, (float)yw - hy);
-                // the up-sampled flow of an output pixel is parked in U, V: the B part adds it to the solve two batches on
-                if (a_out && ye + e >= yo_lo && ye + e < yo_hi) {
-                    Uo[(long long)(ye + e) * a.u.pitch + ax] = uu[e];
-                    Vo[(long long)(ye + e) * a.v.pitch + ax] = vv[e];
-                }
+                w1[e] = remap_bilinear(I1, ip, H, W, (float)t.xw + hx, (float)yw + hy);
+                w2[e] = remap_bilinear(I2, ip, H, W, (float)t.xw - hx, (float)yw - hy);
             }
         } else {
-            w1[0] = I1[(long long)yw0 * ip + axw]; w2[0] = I2[(long long)yw0 * ip + axw];
-            w1[1] = I1[(long long)yw1 * ip + axw]; w2[1] = I2[(long long)yw1 * ip + axw];
+            w1[0] = I1[(long long)yw0 * ip + t.xw]; w2[0] = I2[(long long)yw0 * ip + t.xw];
+            w1[1] = I1[(long long)yw1 * ip + t.xw]; w2[1] = I2[(long long)yw1 * ip + t.xw];
         }
-        s_im[2 * ak][0][ac] = w1[0]; s_im[2 * ak][1][ac] = w2[0];
-        s_im[2 * ak + 1][0][ac] = w1[1]; s_im[2 * ak + 1][1][ac] = w2[1];
-        if (ak == 3) { s_prev[n & 1][0][ac] = w1[1]; s_prev[n & 1][1][ac] = w2[1]; }   // (wave-uniform)
+        s_im[n & 1][2 * t.k][0][t.c] = w1[0]; s_im[n & 1][2 * t.k][1][t.c] = w2[0];
+        s_im[n & 1][2 * t.k + 1][0][t.c] = w1[1]; s_im[n & 1][2 * t.k + 1][1][t.c] = w2[1];
+    };
+    auto wbatch = [&](int n) __attribute__((always_inline)) {     // W wave wv - 5 takes units wv - 5, wv - 2, wv + 1 (< 8)
+        for (int u = wv - 5; u < 8; u += 3) wunit(n, u);
     };
 
-    // ---- phase A, B part: the wave solves its row pair of the sums S(n - 1) left behind -----------------------------
-    auto bpart = [&](int n) __attribute__((always_inline)) {
-        const int yb = ym0 + 8 * (n - 1) + 2 * ak - R; // image row of sums row 2 ak (the pair: yb, yb + 1)
+    // ---- phase B: the wave solves unit wv of the sums S(n) left behind ----------------------------------------------
+    auto bphase = [&](int n) __attribute__((always_inline)) {
+        const Unit t = unit(wv);
+        const int yb = ym0 + 8 * n + 2 * t.k - R;      // image row of sums row 2 k (the pair: yb, yb + 1)
         if (yb + 1 < yo_lo || yb >= yo_hi) return;      // (wave-uniform)
-        [[maybe_unused]] double uu[2] = {0.0, 0.0}, vv[2] = {0.0, 0.0};
-        if constexpr (HAS_UP && !FW) {
-            // (R odd: the pair (yb, yb+1) is (odd, even) -- two coarse pairs; the unfused path is not the hot one)
-            const int xq = min(max(ax, 0), W - 1);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int y = min(max(yb + e, 0), H - 1);
-                double tu[2], tv[2];
-                upflow2(y >> 1, xq, tu, tv);
-                uu[e] = tu[y & 1]; vv[e] = tv[y & 1];
-            }
-        }
+        const int sc = min(max(t.c - (HL + 2), 0), XO - 1);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int yo = yb + e;
-            const bool st = a_out && yo >= yo_lo && yo < yo_hi;
+            const bool st = t.out && yo >= yo_lo && yo < yo_hi;
             double S[5];
 #pragma unroll
-            for (int f = 0; f < 5; ++f) S[f] = s_sums[2 * ak + e][f][ac];
+            for (int f = 0; f < 5; ++f) S[f] = s_sums[2 * t.k + e][f][sc];
             double u, v;
             lk_solve(S, u, v);
             if (st) {
-                double *pu = Uo + (long long)yo * a.u.pitch + ax, *pv = Vo + (long long)yo * a.v.pitch + ax;
-                if constexpr (FW) { u += *pu; v += *pv; }           // parked by the W part of this workgroup
-                else if constexpr (HAS_UP) { u += uu[e]; v += vv[e]; }
+                double *pu = Uo + (long long)yo * a.u.pitch + t.x, *pv = Vo + (long long)yo * a.v.pitch + t.x;
+                if constexpr (HAS_UP) { u += *pu; v += *pv; }       // parked by the W waves of this workgroup
                 __builtin_nontemporal_store(u, pu);
                 __builtin_nontemporal_store(v, pv);
             }
         }
     };
 
-    // ---- phase S state (waves 0..4; the others carry it along unused) ---------------------------------------------
-    const int fw = min(wv, 4);                         // field of this S wave: fx^2, fy^2, fx fy, fx ft, fy ft
+    // zero the pads of the private rows once (only non-output lanes ever read them)
+    for (int k = threadIdx.x; k < 5 * 2 * PAD; k += C::NT) {
+        const int f = k / (2 * PAD), p = k % (2 * PAD);
+        const int e = p < PAD ? p : 64 + p;
+        s_pa[f][e] = 0.0; s_pb[f][e] = 0.0; s_pq[f][e] = 0.0;
+    }
+
+    if (wv >= 5) {
+        // =============================================================================================================
+        // W waves
+        // =============================================================================================================
+        wbatch(0);
+        __syncthreads();
+        for (int n = 0; n < NBS; ++n) {
+            if (n + 1 < NBS) wbatch(n + 1);
+            __syncthreads();                           // sums of batch n and rows of batch n + 1 complete
+            bphase(n);
+            __syncthreads();                           // sums consumed
+        }
+        return;
+    }
+    // =================================================================================================================
+    // S waves
+    // =================================================================================================================
+    const int fw = wv;                                 // field of this S wave: fx^2, fy^2, fx fy, fx ft, fy ft
     // derivative types of the field's two factors: 0 = fx, 1 = fy, 2 = ft.  One image's 2 x 2 filter response in the
     // reference's order (lk_device.h f2d_*): D = ((-p00 + c1 p01) + c2 p10) + c3 p11, the derivative = D(image 1) + sg D(image 2):
     //   fx: c = (+, -, +), sg = +;   fy: c = (-, +, +), sg = +;   ft: c = (-, -, -), sg = -  (f2d_pos(b) == -f2d_neg(b) exactly)
-    // multiplying by +-1.0 inside an FMA rounds exactly where the reference's additions and subtractions round
     const int T1 = (fw == 1 || fw == 4) ? 1 : 0;                       // xx, xy, xt: fx;  yy, yt: fy
     const int T2 = fw == 0 ? 0 : (fw <= 2 ? 1 : 2);                    // xx: fx;  yy, xy: fy;  xt, yt: ft
     const double c11 = T1 == 0 ? 1.0 : -1.0, c12 = T1 == 1 ? 1.0 : -1.0, c13 = T1 == 2 ? -1.0 : 1.0, sg1 = T1 == 2 ? -1.0 : 1.0;
     const double c21 = T2 == 0 ? 1.0 : -1.0, c22 = T2 == 1 ? 1.0 : -1.0, c23 = T2 == 2 ? -1.0 : 1.0, sg2 = T2 == 2 ? -1.0 : 1.0;
-    const double *im_row = &s_im[0][0][2 * lane];
     double *pa_row = &s_pa[fw][PAD + lane], *pb_row = &s_pb[fw][PAD + lane], *pq_row = &s_pq[fw][PAD + lane];
-    double *sums_row = &s_sums[0][fw][2 * lane];
     const int xs = x0 - 2 + 2 * lane;                  // image column of the lane's first column (even: the pair is all in or all out)
     const bool col_in = xs >= 0 && xs < W;
     const bool all_col_in = __builtin_amdgcn_ballot_w64(!col_in) == 0;
+    const bool s_out = 2 * lane >= HL + 2 && 2 * lane < HL + 2 + XO;   // the pair is an output pair of the workgroup
+    double *sums_row = &s_sums[0][fw][min(max(2 * lane - (HL + 2), 0), XO - 2)];
     double ring[L][2], pre[2] = {0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < L; ++q) ring[q][0] = ring[q][1] = 0.0;
-    // the previous marched row: left tap, column a, column b of image 1 (A) and image 2 (B); live inside a batch only
-    double pAl, pAa, pAb, pBl, pBa, pBb;
+    // the previous marched row: left tap, column a, column b of image 1 (A) and image 2 (B)
+    double pAl = 0.0, pAa = 0.0, pAb = 0.0, pBl = 0.0, pBa = 0.0, pBb = 0.0;
 
-    // one marched row at static chunk position KC, batch row RR
-    auto srow = [&](auto kcc, auto rrc, int n) __attribute__((always_inline)) {
-        constexpr int KC = decltype(kcc)::value, RR = decltype(rrc)::value;
+    auto dpp_left = [](double v) __attribute__((always_inline)) {   // lane l <- lane l - 1 (lane 0: 0)
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+    };
+    // the two products of marched row RR of batch n (image rows from LDS, previous row from registers)
+    auto sprod = [&](auto rrc, int n, double &pa, double &pb) __attribute__((always_inline)) {
+        constexpr int RR = decltype(rrc)::value;
         const int i = 8 * n + RR, yy = ym0 + i;
         const bool row_ok = yy >= 0 && yy < H && i >= 1;       // (wave-uniform) row 0 of the march has no previous row
-        const lk_d2 mA = *reinterpret_cast<const lk_d2 *>(im_row + RR * 256);
-        const lk_d2 mB = *reinterpret_cast<const lk_d2 *>(im_row + RR * 256 + 128);
-        const double cAl = dpp_wave_shr1(mA.y), cBl = dpp_wave_shr1(mB.y);   // left tap of column a: the left lane's column b
+        const double *im = &s_im[n & 1][RR][0][2 * lane];
+        const lk_d2 mA = *reinterpret_cast<const lk_d2 *>(im);
+        const lk_d2 mB = *reinterpret_cast<const lk_d2 *>(im + 128);
+        const double cAl = dpp_left(mA.y), cBl = dpp_left(mB.y);   // left tap of column a: the left lane's column b
         auto resp = [&](double k1, double k2, double k3, double p00, double p01, double p10, double p11) __attribute__((always_inline)) {
             return __builtin_fma(k3, p11, __builtin_fma(k2, p10, __builtin_fma(k1, p01, -p00)));
         };
@@ -241,30 +266,39 @@ __global__ __launch_bounds__(512, 4) void lk_batch_kernel(LKArgs a)
         const double g2a = __builtin_fma(sg2, resp(c21, c22, c23, pBl, pBa, cBl, mB.x), resp(c21, c22, c23, pAl, pAa, cAl, mA.x));
         const double g2b = __builtin_fma(sg2, resp(c21, c22, c23, pBa, pBb, mB.x, mB.y), resp(c21, c22, c23, pAa, pAb, mA.x, mA.y));
         pAl = cAl; pAa = mA.x; pAb = mA.y; pBl = cBl; pBa = mB.x; pBb = mB.y;
-        double pa = g1a * g2a, pb = g1b * g2b;
+        pa = g1a * g2a; pb = g1b * g2b;
         if (!(row_ok && all_col_in)) {                  // rows / columns outside the image contribute 0 (wave-uniform test)
             const bool keep = row_ok && col_in;
             pa = keep ? pa : 0.0; pb = keep ? pb : 0.0;
         }
-        // horizontal windows of the pair through the wave's private row (in-order LDS: no barrier, no wait)
-        // (the fences are compiler-only: seen from ONE thread the stores and the neighbours' loads do not alias, so
-        // nothing else keeps the compiler from moving a load above the store of the lane it reads from)
+    };
+    struct HRow { double q[NQ], sb, sa; };
+    // (the fences are compiler-only: seen from ONE thread the stores and the neighbours' loads do not alias, so nothing
+    // else keeps the compiler from moving a load above the store of the lane it reads from; the LDS itself executes a
+    // wave's instructions in order, so neither a barrier nor a wait is needed, and row r + 1 may overwrite the private row
+    // as soon as the reads of row r have been ISSUED)
+    auto hpublish = [&](double pa, double pb) __attribute__((always_inline)) {
+        BT_WAVE_FENCE();
         pa_row[0] = pa; pb_row[0] = pb; pq_row[0] = pa + pb;
         BT_WAVE_FENCE();
-        double q[NQ];
+    };
+    auto hgather = [&](HRow &h) __attribute__((always_inline)) {
 #pragma unroll
-        for (int d = 0; d < NQ; ++d) q[d] = pq_row[d - QH];
-        const double sb = pb_row[-HS], sa = pa_row[HS];
+        for (int d = 0; d < NQ; ++d) h.q[d] = pq_row[d - QH];
+        h.sb = pb_row[-HS]; h.sa = pa_row[HS];
         BT_WAVE_FENCE();
+    };
+    // horizontal windows of the pair + vertical van Herk step at static chunk position KC -> sums row RR
+    auto svert = [&](auto kcc, auto rrc, const HRow &h) __attribute__((always_inline)) {
+        constexpr int KC = decltype(kcc)::value, RR = decltype(rrc)::value;
         double hs[2];
         if constexpr (C::RODD) {
-            const double shared = split_tree<0, NQ - 1>(q);
-            hs[0] = sb + shared; hs[1] = shared + sa;
+            const double shared = split_tree<0, NQ - 1>(h.q);
+            hs[0] = h.sb + shared; hs[1] = shared + h.sa;
         } else {
-            const double shared = split_tree<1, NQ - 2>(q);
-            hs[0] = (q[0] + shared) + sa; hs[1] = (sb + shared) + q[NQ - 1];
+            const double shared = split_tree<1, NQ - 2>(h.q);
+            hs[0] = (h.q[0] + shared) + h.sa; hs[1] = (h.sb + shared) + h.q[NQ - 1];
         }
-        // vertical window: van Herk ring, chunks of L = WIN + 1 rows
         lk_d2 o;
         double S[2];
 #pragma unroll
@@ -280,40 +314,39 @@ __global__ __launch_bounds__(512, 4) void lk_batch_kernel(LKArgs a)
             }
         }
         o.x = S[0]; o.y = S[1];
-        *reinterpret_cast<lk_d2 *>(sums_row + RR * 640) = o;
+        if (s_out) *reinterpret_cast<lk_d2 *>(sums_row + RR * (5 * XO)) = o;
+    };
+    // two marched rows per LDS round trip: both rows' products, then publish / gather row 0 and row 1 back to back
+    // (one private row: the LDS executes them in order), then both rows' sums
+    auto srow2 = [&](auto kcc, auto rrc, int n) __attribute__((always_inline)) {
+        constexpr int KC = decltype(kcc)::value, RR = decltype(rrc)::value;
+        double pa0, pb0, pa1, pb1;
+        sprod(std::integral_constant<int, RR>{}, n, pa0, pb0);
+        sprod(std::integral_constant<int, RR + 1>{}, n, pa1, pb1);
+        HRow h0, h1;
+        hpublish(pa0, pb0); hgather(h0);
+        hpublish(pa1, pb1); hgather(h1);
+        svert(std::integral_constant<int, KC>{}, std::integral_constant<int, RR>{}, h0);
+        svert(std::integral_constant<int, (KC + 1) % L>{}, std::integral_constant<int, RR + 1>{}, h1);
     };
     auto sbatch = [&](auto vc, int n) __attribute__((always_inline)) {
         constexpr int V = decltype(vc)::value;
-        {   // the row above the batch (batch 0: stale memory -- row 0 of the march is zeroed anyway)
-            const lk_d2 mA = *reinterpret_cast<const lk_d2 *>(&s_prev[(n + 1) & 1][0][2 * lane]);
-            const lk_d2 mB = *reinterpret_cast<const lk_d2 *>(&s_prev[(n + 1) & 1][1][2 * lane]);
-            pAl = dpp_wave_shr1(mA.y); pAa = mA.x; pAb = mA.y; pBl = dpp_wave_shr1(mB.y); pBa = mB.x; pBb = mB.y;
-        }
-        [&]<int... Rs>(std::integer_sequence<int, Rs...>) __attribute__((always_inline)) {
-            (srow(std::integral_constant<int, (8 * V + Rs) % L>{}, std::integral_constant<int, Rs>{}, n), ...);
-        }(std::make_integer_sequence<int, 8>{});
+        [&]<int... Ts>(std::integer_sequence<int, Ts...>) __attribute__((always_inline)) {
+            (srow2(std::integral_constant<int, (8 * V + 2 * Ts) % L>{}, std::integral_constant<int, 2 * Ts>{}, n), ...);
+        }(std::make_integer_sequence<int, 4>{});
     };
-
-    // zero the pads of the private rows once (only non-output lanes ever read them)
-    for (int k = threadIdx.x; k < 5 * 2 * PAD; k += C::NT) {
-        const int f = k / (2 * PAD), p = k % (2 * PAD);
-        const int e = p < PAD ? p : 64 + p;
-        s_pa[f][e] = 0.0; s_pb[f][e] = 0.0; s_pq[f][e] = 0.0;
-    }
 
     constexpr int LCM = 8 * C::NV;
     int v = (((ym0 % LCM) + LCM) % LCM) >> 3;          // variant of batch 0: chunk position of marched row 0 = 8 v mod L
-    for (int n = 0; n <= NBS; ++n) {
-        if (n < NBS) wpart(n);
-        if (n >= 1) bpart(n);
-        __syncthreads();                               // rows of batch n complete; sums of batch n - 1 consumed
-        if (n < NBS && wv < 5) {
-            [&]<int... Vs>(std::integer_sequence<int, Vs...>) __attribute__((always_inline)) {
-                ((v == Vs ? (sbatch(std::integral_constant<int, Vs>{}, n), 0) : 0), ...);
-            }(std::make_integer_sequence<int, C::NV>{});
-        }
+    __syncthreads();                                   // rows of batch 0 complete (W waves' prologue)
+    for (int n = 0; n < NBS; ++n) {
+        [&]<int... Vs>(std::integer_sequence<int, Vs...>) __attribute__((always_inline)) {
+            ((v == Vs ? (sbatch(std::integral_constant<int, Vs>{}, n), 0) : 0), ...);
+        }(std::make_integer_sequence<int, C::NV>{});
         v = v + 1 == C::NV ? 0 : v + 1;
-        __syncthreads();                               // sums of batch n complete; rows free
+        __syncthreads();                               // sums of batch n and rows of batch n + 1 complete
+        bphase(n);
+        __syncthreads();                               // sums consumed
     }
 }
 

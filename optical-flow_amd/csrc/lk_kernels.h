@@ -204,9 +204,12 @@ __global__ __launch_bounds__(256, LK_WARP_WAVES) void warp_kernel(WarpArgs a)
     const __amdgpu_buffer_rsrc_t rCV = buf_rsrc(a.cv.at(p) + (long long)crow_lo * a.cv.pitch, ((long long)(Hc - 1 - crow_lo) * a.cv.pitch + Wc) * 8);
     auto srow = [&](int k) { return (k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k)) - crow_lo; };   // r101(2k,2Hc)/2
     auto htap = [&](__amdgpu_buffer_rsrc_t r, int so) __attribute__((always_inline)) -> double {
-        const double A = buf_ld(r, jm8, so), B = buf_ld(r, jc8, so), C = buf_ld(r, jp8, so);
+        const double A0 = buf_ld(r, jm8, so), B = buf_ld(r, jc8, so), C0 = buf_ld(r, jp8, so);
+        // a tap with weight 0 is one cv::pyrUp does not read (image borders): dropped before the multiplication, so
+        // that a non-finite flow value spreads exactly as far as in the reference
+        const double A = wAf != 0.0f ? A0 : 0.0, C = wCf != 0.0f ? C0 : 0.0;
         const double ev = (A * (double)wAf + B * (double)mBf) + C * (double)wCf;
-        const double od = (B + (dup ? B : C)) * 4;
+        const double od = (B + (dup ? B : C0)) * 4;
         return odd ? od : ev;
     };
 

@@ -60,9 +60,13 @@ __device__ __forceinline__ UpSel1 make_upsel1(int x, int Wc)
     }
     return s;
 }
+// A tap with weight 0 is a tap cv::pyrUp does not read: it is dropped BEFORE the multiplication, so that a non-finite
+// coarse flow value (a division by a denormal determinant) spreads exactly as far as in the reference (Inf * 0 would
+// turn the neighbouring columns into NaN).  The comparisons are loop-invariant per lane.
 __device__ __forceinline__ double pyrup_h1v(double A, double B, double C, const UpSel1 &s)
 {
-    return __builtin_fma(C, s.wC, __builtin_fma(A, s.wA, B * s.wB));
+    const double a = s.wA != 0.0 ? A : 0.0, c = s.wC != 0.0 ? C : 0.0;
+    return __builtin_fma(c, s.wC, __builtin_fma(a, s.wA, B * s.wB));
 }
 
 template <int WIN, int TX, bool HAS_UP>

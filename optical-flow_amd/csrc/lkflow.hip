@@ -55,7 +55,7 @@ struct Level {
 }  // namespace
 
 #ifndef LKFLOW_SPLIT_FUSED_DEFAULT
-#define LKFLOW_SPLIT_FUSED_DEFAULT 1                 /* A/B builds: -DLKFLOW_SPLIT_FUSED_DEFAULT=1 */
+#define LKFLOW_SPLIT_FUSED_DEFAULT 0                 /* A/B builds: -DLKFLOW_SPLIT_FUSED_DEFAULT=1 */
 #endif
 struct lkflow_ctx {
     int device = 0;
@@ -68,6 +68,7 @@ struct lkflow_ctx {
     // options
     int impl = 0;
     int fuse_warp = LKFLOW_SPLIT_FUSED_DEFAULT;   // LKFLOW_OPT_FUSE_WARP
+    int lk_batch = 0;                             // LKFLOW_OPT_LK_BATCH
     int tile_rows = 0;
     int profile = 0;
     struct Rec { hipEvent_t a, b; int slot; };
@@ -541,14 +542,11 @@ int launch_batch_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, bool fw, int pa
     return LKFLOW_OK;
 }
 
-// windows the batch-synchronous kernel is built for (<= 128 VGPRs with the WIN x 4 register ring)
+// windows the batch-synchronous kernel is built for (<= 128 VGPRs with the WIN x 4 register ring); opt-in (LKFLOW_OPT_LK_BATCH)
 bool batch_applies(const lkflow_ctx *ctx, int win, int W, int H)
 {
-#ifndef LKFLOW_BATCH_DEFAULT
-#define LKFLOW_BATCH_DEFAULT 0                       /* until it beats warp + lk_split on the box */
-#endif
-    static const int on = knob("LKFLOW_BATCH", LKFLOW_BATCH_DEFAULT);   // A/B
-    return on && ctx->impl == 0 && win >= 5 && win <= 15 && !(W & 1) && !(H & 1) && W >= 2 && H > win / 2 + 3;
+    static const int env = knob("LKFLOW_BATCH", -1);   // A/B: overrides the option
+    return (env >= 0 ? env : ctx->lk_batch) && ctx->impl == 0 && win >= 5 && win <= 15 && !(W & 1) && !(H & 1) && W >= 2 && H > win / 2 + 3;
 }
 
 int launch_batch(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, bool fw, int pairs, int win, hipStream_t s, int stage, int level)
@@ -657,8 +655,7 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
         if (win == 3 && !no_x2 && a.W >= 2 && !(a.W & 1)) rc = launch_w3x2(ctx, a, has_up, pairs, s);   // 2 columns per lane
         else if (win == 3 && !no_w3) rc = launch_lk3_win<3, 64>(ctx, a, has_up, pairs, s);   // barrier-free DPP kernel
         else {
-            static const int batch_lk = knob("LKFLOW_BATCH_LK", 1);   // A/B: 0 = wave-specialised kernel for plain (unfused) LK levels
-            rc = (batch_lk && batch_applies(ctx, win, a.W, a.H)) ? launch_batch(ctx, a, has_up, false, pairs, win, s, -1, 0) : LK_NOT_TAKEN;
+            rc = batch_applies(ctx, win, a.W, a.H) ? launch_batch(ctx, a, has_up, false, pairs, win, s, -1, 0) : LK_NOT_TAKEN;
             if (rc == LK_NOT_TAKEN)
                 rc = split_applies(win, a.W, a.H) ? launch_split(ctx, a, has_up, pairs, win, s) : LK_NOT_TAKEN;
             if (rc == LK_NOT_TAKEN)
@@ -816,6 +813,10 @@ int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value)
             if (value < 0 || value > 1) return LKFLOW_E_ARG;
             ctx->fuse_warp = value;
             return LKFLOW_OK;
+        case LKFLOW_OPT_LK_BATCH:
+            if (value < 0 || value > 1) return LKFLOW_E_ARG;
+            ctx->lk_batch = value;
+            return LKFLOW_OK;
         case LKFLOW_OPT_TILE_ROWS:
             if (value < 0 || value > 4096) return LKFLOW_E_ARG;
             ctx->tile_rows = value;
@@ -894,6 +895,30 @@ int lkflow_lk_batch_f64_dev(lkflow_ctx *ctx, const double *img1, const double *i
     return launch_lk(ctx, a, false, n_pairs, win, (hipStream_t)stream);
 }
 
+int lkflow_lk_up_batch_f64_dev(lkflow_ctx *ctx, const double *img1, const double *img2, size_t s1, size_t s2, int n_pairs,
+                               int rows, int cols, size_t step_bytes, const double *cu, const double *cv, size_t c_ps,
+                               size_t c_step_bytes, double *U, double *V, size_t uv_pair_stride_bytes, size_t uv_step_bytes,
+                               int win, void *stream)
+{
+    if (!ctx || !img1 || !img2 || !cu || !cv || !U || !V) return LKFLOW_E_ARG;
+    int rc = check_common(rows, cols, step_bytes, uv_step_bytes, n_pairs);
+    if (rc) return rc;
+    if ((rows & 1) || (cols & 1)) return LKFLOW_E_ARG;       // a level below the coarsest is twice its coarser level
+    if (s1 % 8 || s2 % 8 || uv_pair_stride_bytes % 8 || c_ps % 8 || c_step_bytes % 8 || c_step_bytes < (size_t)(cols / 2) * 8)
+        return LKFLOW_E_ARG;
+    if ((rc = check_win(win))) return rc;
+    if ((rc = set_device(ctx))) return rc;
+    lk::LKArgs a{};
+    a.i1 = {img1, (long long)(s1 / 8), (long long)(step_bytes / 8)};
+    a.i2 = {img2, (long long)(s2 / 8), (long long)(step_bytes / 8)};
+    a.cu = {cu, (long long)(c_ps / 8), (long long)(c_step_bytes / 8)};
+    a.cv = {cv, (long long)(c_ps / 8), (long long)(c_step_bytes / 8)};
+    a.u = {U, (long long)(uv_pair_stride_bytes / 8), (long long)(uv_step_bytes / 8)};
+    a.v = {V, (long long)(uv_pair_stride_bytes / 8), (long long)(uv_step_bytes / 8)};
+    a.H = rows; a.W = cols;
+    return launch_lk(ctx, a, true, n_pairs, win, (hipStream_t)stream);
+}
+
 // ---- full pyramid ------------------------------------------------------------------------------
 int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, size_t prev_ps,
                                  size_t next_ps, int n_pairs, int rows, int cols, size_t step_bytes,
@@ -909,9 +934,15 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
     if (pyr_levels < 1 || pyr_levels > max_levels(cols, rows)) return LKFLOW_E_LEVELS;
     if ((rc = check_win(win))) return rc;
     if ((rc = set_device(ctx))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // An enqueued host-buffer pair (lkflow_enqueue_pair_*) works in this context's arena on the context's own stream:
+    // a call on any OTHER stream must not carve or overwrite the arena under it (lkflow.h: one pair per context in flight).
+    if (ctx->host_inflight && s != ctx->own_stream) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->own_stream));
+        ctx->host_inflight = false;
+    }
     if ((rc = ensure_workspace(ctx, rows, cols, pyr_levels, n_pairs))) return rc;
 
-    hipStream_t s = (hipStream_t)stream;
     const int L = pyr_levels, P = n_pairs;
     const std::vector<Level> &lv = ctx->lv;
     const long long step = (long long)(step_bytes / 8);
@@ -1083,6 +1114,9 @@ static int enqueue_host_pair(lkflow_ctx *ctx, const void *prev, const void *next
     pin_host_range(ctx, next, (size_t)(rows - 1) * step_bytes + (size_t)cols * esz);
     pin_host_range(ctx, U, (size_t)(rows - 1) * uv_step_bytes + row_b);
     pin_host_range(ctx, V, (size_t)(rows - 1) * uv_step_bytes + row_b);
+    // from here on copies may be in flight on the caller's buffers: any failure drains the stream before returning
+    struct Drain { lkflow_ctx *c; hipStream_t st; bool armed = true; ~Drain() { if (armed) { (void)hipStreamSynchronize(st); c->host_inflight = false; } } } drain{ctx, s};
+    ctx->host_inflight = true;
     if (u8) {
         unsigned char *d8 = reinterpret_cast<unsigned char *>(d_v + npx);       // [prev | next], contiguous
         HIP_TRY(ctx, hipMemcpy2DAsync(d8, cols, prev, step_bytes, cols, rows, hipMemcpyHostToDevice, s));
@@ -1101,7 +1135,7 @@ static int enqueue_host_pair(lkflow_ctx *ctx, const void *prev, const void *next
         HIP_TRY(ctx, hipMemcpy2DAsync(const_cast<void *>(prev), step_bytes, d_prev, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipMemcpy2DAsync(const_cast<void *>(next), step_bytes, d_next, row_b, row_b, rows, hipMemcpyDeviceToHost, s));
     }
-    ctx->host_inflight = true;
+    drain.armed = false;
     return LKFLOW_OK;
 }
 

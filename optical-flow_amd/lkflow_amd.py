@@ -35,6 +35,7 @@ LKFLOW_OPT_TILE_ROWS = 2
 LKFLOW_OPT_PROFILE = 3
 LKFLOW_OPT_PIN_HOST = 4
 LKFLOW_OPT_FUSE_WARP = 5
+LKFLOW_OPT_LK_BATCH = 6
 LKFLOW_STAGE_PYRDOWN, LKFLOW_STAGE_WARP, LKFLOW_STAGE_LK = 0, 1, 2
 LKFLOW_N_STAGES, LKFLOW_MAX_LEVELS = 3, 32
 
@@ -67,6 +68,8 @@ SIGNATURES = {
                                           _sz, _i, _i, _u, _vp]),
     "lkflow_lk_batch_f64_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _i, _i, _sz, _vp, _vp, _sz, _sz, _i,
                                      _vp]),
+    "lkflow_lk_up_batch_f64_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _i, _i, _sz, _vp, _vp, _sz, _sz, _vp, _vp, _sz, _sz,
+                                        _i, _vp]),
     "lkflow_pyrdown_f64_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _vp, _sz, _sz, _vp]),
     "lkflow_pyrup_f64_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _vp, _sz, _sz, _vp]),
     "lkflow_warp_f64_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _vp, _vp, _sz, _sz, _vp, _vp,
@@ -361,6 +364,23 @@ class Context:
             self._h, img1.data_ptr(), img2.data_ptr(), img1.stride(0) * 8, img2.stride(0) * 8, P, H, W,
             img1.stride(1) * 8, U.data_ptr(), V.data_ptr(), U.stride(0) * 8, U.stride(1) * 8, int(win),
             _stream_ptr(stream))
+        self._chk(rc)
+        return U, V
+
+    def lk_up_batch(self, img1, img2, cu, cv, win=3, stream=None):
+        """Single-level LK + "+= pyrUp(coarse flow)" (ParallelVideoPyr.cpp:634-637): img [P, H, W], cu / cv [P, H/2, W/2]."""
+        torch = _torch()
+        for t, n in ((img1, "img1"), (img2, "img2"), (cu, "cu"), (cv, "cv")):
+            _check_dev(t, n)
+        P, H, W = img1.shape
+        assert img2.shape == img1.shape and img2.stride(1) == img1.stride(1)
+        assert cu.shape == (P, H // 2, W // 2) and cv.shape == cu.shape and cu.stride() == cv.stride()
+        U = torch.empty((P, H, W), dtype=torch.float64, device=img1.device)
+        V = torch.empty_like(U)
+        rc = lib().lkflow_lk_up_batch_f64_dev(
+            self._h, img1.data_ptr(), img2.data_ptr(), img1.stride(0) * 8, img2.stride(0) * 8, P, H, W,
+            img1.stride(1) * 8, cu.data_ptr(), cv.data_ptr(), cu.stride(0) * 8, cu.stride(1) * 8,
+            U.data_ptr(), V.data_ptr(), U.stride(0) * 8, U.stride(1) * 8, int(win), _stream_ptr(stream))
         self._chk(rc)
         return U, V
 

@@ -30,18 +30,41 @@ def test_usable_cores_is_what_the_scheduler_allows():
 
 
 def test_committed_pmc_traffic_is_usable_by_bench():
-    """roofline.traffic comes from profiles/pmc_traffic.json: the committed file must be tagged with the headline
-    workload and give a per-launch figure between the algorithmic bytes and twice that (aprons, halos)."""
+    """roofline.traffic comes from profiles/pmc_traffic.json: the committed file is tagged with the headline workload and
+    with the digest of the kernel sources it was measured on.  On matching code it must give a per-launch figure between
+    the algorithmic bytes and twice that (aprons, halos); on any other code -- or workload -- bench.py must report null
+    rather than a stale number."""
+    import json
     import bench
     cols, rows, levels, win, pairs = bench.CONFIGS["1080p"]
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-        import json
-        names = [k for k in json.load(fh) if k.startswith("lk::lk_") and ", true" in k]     # HAS_UP instantiations
+        rec = json.load(fh)
+    names = [k for k in rec if k.startswith("lk::lk_") and ", true" in k]     # HAS_UP instantiations
     assert names, "no level-0 LK kernel in profiles/pmc_traffic.json"
-    sys.path.insert(0, os.path.join(ROOT, "optical-flow_amd"))
-    import lkflow_amd                                        # the name bench.py looks up is the one rocprofv3 printed
-    assert lkflow_amd.lk_kernel_name(rows, cols, win, has_up=True) in names
-    alg = bench.lk0_bytes_per_pair(cols, rows, levels) * pairs
+    assert rec.get("_workload") == f"{cols}x{rows}x{pairs}"
     ts = [bench.measured_traffic(k, cols, rows, pairs) for k in names]
-    assert any(t is not None and alg <= t <= 2 * alg for t in ts)
+    if rec.get("_csrc_sha") == bench.csrc_digest():
+        sys.path.insert(0, os.path.join(ROOT, "optical-flow_amd"))
+        import lkflow_amd                                    # the name bench.py looks up is the one rocprofv3 printed
+        assert lkflow_amd.lk_kernel_name(rows, cols, win, has_up=True) in names
+        alg = bench.lk0_bytes_per_pair(cols, rows, levels) * pairs
+        assert any(t is not None and alg <= t <= 2 * alg for t in ts)
+        assert any(bench.rocprof_avg_launch_ms(k, cols, rows, pairs) for k in names)
+    else:
+        assert all(t is None for t in ts)                    # measured on other code: not reported
     assert all(bench.measured_traffic(k, cols, rows, pairs + 1) is None for k in names)   # other workloads: null
+
+
+def test_csrc_digest_follows_the_kernel_sources(tmp_path, monkeypatch):
+    import bench
+    d0 = bench.csrc_digest()
+    assert len(d0) == 16 and d0 == bench.csrc_digest()
+    fake = tmp_path / "repo"
+    (fake / "optical-flow_amd" / "csrc").mkdir(parents=True)
+    (fake / "include").mkdir()
+    (fake / "optical-flow_amd" / "csrc" / "k.h").write_text("a")
+    (fake / "include" / "lkflow.h").write_text("h")
+    monkeypatch.setattr(bench, "ROOT", str(fake))
+    d1 = bench.csrc_digest()
+    (fake / "optical-flow_amd" / "csrc" / "k.h").write_text("b")
+    assert bench.csrc_digest() != d1 and d1 != d0

@@ -23,5 +23,5 @@ for P in "${PASSES[@]}"; do
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python3 $R/bench.py --no-extras "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
   i=$((i+1))
 done
-python3 $R/tools/pmc_summary.py $OUT $R/gpurun_out/pmc_${TAG}_traffic.json ${WORKLOAD:-1920x1080x32} > $R/gpurun_out/pmc_$TAG.txt 2>&1
+python3 $R/tools/pmc_summary.py $OUT $R/gpurun_out/pmc_${TAG}_traffic.json ${WORKLOAD:-1920x1080x32} ${TRACE_BY_GRID:-} > $R/gpurun_out/pmc_$TAG.txt 2>&1
 cat $R/gpurun_out/pmc_$TAG.txt

@@ -19,9 +19,9 @@ for cfg in 1080p 4k webcam; do
   rm -rf $OUT/kt_$cfg
 done
 cd $R
-WORKLOAD=1920x1080x32 bash tools/prof_pmc.sh ${TAG}_1080p --steps 3 --warmup 1 > /dev/null
-WORKLOAD=3840x2160x8 bash tools/prof_pmc.sh ${TAG}_4k --config 4k --steps 3 --warmup 1 > /dev/null
-WORKLOAD=1080x1080x48 bash tools/prof_pmc.sh ${TAG}_webcam --config webcam --steps 3 --warmup 1 > /dev/null
+TRACE_BY_GRID=$OUT/${TAG}_1080p_kernel_trace_by_grid.csv WORKLOAD=1920x1080x32 bash tools/prof_pmc.sh ${TAG}_1080p --steps 3 --warmup 1 > /dev/null
+TRACE_BY_GRID=$OUT/${TAG}_4k_kernel_trace_by_grid.csv WORKLOAD=3840x2160x8 bash tools/prof_pmc.sh ${TAG}_4k --config 4k --steps 3 --warmup 1 > /dev/null
+TRACE_BY_GRID=$OUT/${TAG}_webcam_kernel_trace_by_grid.csv WORKLOAD=1080x1080x48 bash tools/prof_pmc.sh ${TAG}_webcam --config webcam --steps 3 --warmup 1 > /dev/null
 for cfg in 1080p 4k webcam; do
   cp gpurun_out/pmc_${TAG}_$cfg.txt $OUT/${TAG}_${cfg}_pmc_summary.txt
   cp gpurun_out/pmc_${TAG}_${cfg}_traffic.json $OUT/${TAG}_${cfg}_pmc_traffic.json
