@@ -21,6 +21,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "lkflow.h"
 
@@ -111,19 +112,50 @@ public:
     void enqueue(const Mat &prev, const Mat &next, Mat &U, Mat &V, int pyr_levels, int win = 3, unsigned flags = 0)
     {
         check_pair(prev, next);
+        finish_staged();
         seat_outputs(U, V, prev.rows, prev.cols);
-        check(lkflow_enqueue_pair_f64(ctx_, mat_data(prev), mat_data(next), prev.rows, prev.cols, mat_step(prev),
+        double *nx = mat_data(next);
+        if (mat_step(next) != mat_step(prev)) {
+            // The reference takes any two CV_64FC1 Mats of one size (a ROI next to a continuous matrix); the C ABI describes
+            // the pair with ONE row step: `next` goes through an engine-owned buffer with prev's step (and comes back from
+            // it after the call when the level-0 warp overwrites the inputs, ParallelVideoPyr.cpp:696,701).
+            const size_t st = mat_step(prev), row = (size_t)prev.cols * sizeof(double);
+            staged_.assign((size_t)prev.rows * st / sizeof(double) + 1, 0.0);
+            for (int y = 0; y < prev.rows; ++y)
+                std::memcpy(reinterpret_cast<unsigned char *>(staged_.data()) + (size_t)y * st,
+                            reinterpret_cast<const unsigned char *>(mat_data(next)) + (size_t)y * mat_step(next), row);
+            nx = staged_.data();
+            if (flags & LKFLOW_MUTATE_INPUTS) {
+                back_dst_ = reinterpret_cast<unsigned char *>(mat_data(next)); back_step_ = mat_step(next);
+                back_rows_ = prev.rows; back_row_bytes_ = row; back_src_step_ = st;
+            }
+        }
+        check(lkflow_enqueue_pair_f64(ctx_, mat_data(prev), nx, prev.rows, prev.cols, mat_step(prev),
                                       mat_data(U), mat_data(V), mat_step(U), pyr_levels, win, flags));
     }
-    void wait() { check(lkflow_wait(ctx_)); }
+    void wait()
+    {
+        check(lkflow_wait(ctx_));
+        finish_staged();
+    }
     // Page-lock the (re-used) Mats of a video loop in place: see LKFLOW_OPT_PIN_HOST in lkflow.h.
     void pinHostBuffers(bool on) { check(lkflow_ctx_set_option(ctx_, LKFLOW_OPT_PIN_HOST, on ? 1 : 0)); }
 
     void getLucasKanadeOpticalFlow(const Mat &img1, const Mat &img2, Mat &u, Mat &v, int win = 3)
     {
         check_pair(img1, img2);
+        finish_staged();
         seat_outputs(u, v, img1.rows, img1.cols);
-        check(lkflow_lk_f64(ctx_, mat_data(img1), mat_data(img2), img1.rows, img1.cols, mat_step(img1),
+        const double *p2 = mat_data(img2);
+        if (mat_step(img2) != mat_step(img1)) {              // (as in enqueue(): one row step per pair in the C ABI)
+            const size_t st = mat_step(img1), row = (size_t)img1.cols * sizeof(double);
+            staged_.assign((size_t)img1.rows * st / sizeof(double) + 1, 0.0);
+            for (int y = 0; y < img1.rows; ++y)
+                std::memcpy(reinterpret_cast<unsigned char *>(staged_.data()) + (size_t)y * st,
+                            reinterpret_cast<const unsigned char *>(mat_data(img2)) + (size_t)y * mat_step(img2), row);
+            p2 = staged_.data();
+        }
+        check(lkflow_lk_f64(ctx_, mat_data(img1), p2, img1.rows, img1.cols, mat_step(img1),
                             mat_data(u), mat_data(v), mat_step(u), win));
     }
 
@@ -145,8 +177,8 @@ private:
     static void check_pair(const Mat &a, const Mat &b)
     {
         if (!mat_ok(a) || !mat_ok(b)) throw std::invalid_argument("lkflow: images must be non-empty CV_64FC1");
-        if (a.rows != b.rows || a.cols != b.cols || mat_step(a) != mat_step(b))
-            throw std::invalid_argument("lkflow: image pair must have equal size and step");
+        if (a.rows != b.rows || a.cols != b.cols)
+            throw std::invalid_argument("lkflow: image pair must have equal size");
     }
     void check(int rc) const
     {
@@ -156,7 +188,21 @@ private:
             throw std::runtime_error(msg + " [" + lkflow_last_error(ctx_) + "]");
         throw std::invalid_argument(msg);
     }
+    // copy a staged, overwritten `next` back into the caller's matrix (LKFLOW_MUTATE_INPUTS with unequal steps)
+    void finish_staged()
+    {
+        if (back_dst_) {
+            for (int y = 0; y < back_rows_; ++y)
+                std::memcpy(back_dst_ + (size_t)y * back_step_,
+                            reinterpret_cast<const unsigned char *>(staged_.data()) + (size_t)y * back_src_step_, back_row_bytes_);
+            back_dst_ = nullptr;
+        }
+    }
     lkflow_ctx *ctx_ = nullptr;
+    std::vector<double> staged_;
+    unsigned char *back_dst_ = nullptr;
+    size_t back_step_ = 0, back_src_step_ = 0, back_row_bytes_ = 0;
+    int back_rows_ = 0;
 };
 
 inline Engine &default_engine()

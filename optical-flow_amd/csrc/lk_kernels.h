@@ -253,7 +253,6 @@ struct LKArgs {
     int gx, gy;       // lk_split: column blocks / row strips per pair (1-D grid, XCD-aware tile order)
     unsigned nmain;   // lk_split: marching workgroups; workgroups nmain .. gridDim.x - 1 do the frame pixels (0: separate launch)
     unsigned nbb;     // lk_split: frame workgroups per pair
-    unsigned long long *dbg;   // diagnostic builds only (LK3_STAMPS): per-wave segment cycle totals
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -187,12 +187,7 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
 
     // One marched row at chunk position K (compile-time): the chunk loop below is unrolled WIN
     // times so that every ring access is a plain register (no dispatch, no copies).
-#ifdef LK3_STAMPS
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
-#define LK3_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
-#else
 #define LK3_STAMP(var)
-#endif
     auto row = [&](auto kc, int i) __attribute__((always_inline)) {
         constexpr int K = decltype(kc)::value;
         LK3_STAMP(t0);
@@ -291,9 +286,6 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         // rotate: the only wait for the prefetch
         pa0 = ca0; pa1 = ca1; pb0 = cb0; pb1 = cb1;
         ca0 = qa0[(K + 1) % PF]; ca1 = qa1[(K + 1) % PF]; cb0 = qb0[(K + 1) % PF]; cb1 = qb1[(K + 1) % PF];
-#ifdef LK3_STAMPS
-        asm volatile("" :: "v"(pa0), "v"(ca0), "v"(ca1), "v"(cb0), "v"(cb1));
-#endif
         LK3_STAMP(t5);
 
         if (out_row && is_out) {
@@ -338,10 +330,6 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
             buf_st(rU, vxo, (y - y0) * upb, u);
             buf_st(rV, vxo, (y - y0) * vpb, v);
         }
-#ifdef LK3_STAMPS
-        LK3_STAMP(t6);
-        seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2; seg[3] += t4 - t3; seg[4] += t5 - t4; seg[5] += t6 - t5;
-#endif
     };
 
     // The van Herk chunks are anchored to ABSOLUTE image rows (chunk position of image row r = r mod WIN), not to
@@ -355,14 +343,6 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
             ((base + Ks >= kc0 && base + Ks < nmarch + kc0 ? (row(std::integral_constant<int, Ks>{}, base + Ks - kc0), 0) : 0), ...);
         }(std::make_integer_sequence<int, WIN>{});
     }
-#ifdef LK3_STAMPS
-    // diagnostic build only: per-segment cycle totals of wave 0 of every block -> debug buffer (a.dbg)
-    if (a.dbg && (threadIdx.x & 63) == 0) {
-        const unsigned wid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (TX / 64) + (threadIdx.x >> 6);
-        for (int k = 0; k < 6; ++k) a.dbg[wid * 8 + k] = seg[k];
-        a.dbg[wid * 8 + 6] = nmarch;
-    }
-#endif
 }
 
 }  // namespace lk

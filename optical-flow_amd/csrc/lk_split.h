@@ -43,8 +43,9 @@
 //
 // Only additions in the window sums (flat regions give exactly 0 like the reference); same products, solve and pyrUp
 // expressions as lk_march3.h.  Host-checked: W and H even, H > R + PF + 1, even strip height (a step's row pair is an
-// even and an odd output row); other shapes take lk_march3.h.  -DLK_SPLIT_STAMPS / -DLK_SPLIT_ABL_* are diagnostic
-// builds (per-role cycle stamps; timing-only ablations whose results are wrong by design) -- see DESIGN.md section 4.
+// even and an odd output row); other shapes take lk_march3.h.  (The per-role cycle stamps and the timing-only ablation
+// builds of round 2 -- results wrong by design -- are gone from this header; they are in the git history, r02, and their
+// records under profiles/r02_*.)
 #pragma once
 #include "lk_w3x2.h"     // buf_ld2 (16-byte buffer loads), lk_march3.h
 
@@ -61,21 +62,7 @@
 #define LK_SPLIT_TD 2    /* even: row pairs of coarse taps a B lane keeps in flight (4 spills at 15x15 and is slower) */
 #endif
 
-#ifdef LK_SPLIT_STAMPS   /* diagnostic build: per-wave segment cycle totals -> a.dbg (tools/split_stamps_summary.py) */
-#define SP_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
-#define SP_ACC(k, a, b) seg[k] += (b) - (a)
-#else
-#define SP_STAMP(var)
-#define SP_ACC(k, a, b)
-#endif
 
-#ifdef LK_SPLIT_ABL_RAWBAR   /* timing-only ablation build: barrier without the LDS write drain (results are wrong) */
-#define SP_BARRIER() __builtin_amdgcn_s_barrier()
-#elif defined(LK_SPLIT_ABL_NOBAR) /* timing-only ablation build: no barrier in the role loops at all (results are wrong) */
-#define SP_BARRIER() asm volatile("" ::: "memory")
-#else
-#define SP_BARRIER() __syncthreads()
-#endif
 
 namespace lk {
 
@@ -84,10 +71,7 @@ typedef double lk_d2 __attribute__((ext_vector_type(2)));
 template <int WIN, int K, bool FW = false>
 struct SplitCfg {
     static constexpr int R = WIN / 2;
-#ifndef LK_SPLIT_IDLE_WAVES
-#define LK_SPLIT_IDLE_WAVES 0    /* diagnostic: extra waves that only take part in the barriers (how do 10-wave blocks share a CU?) */
-#endif
-    static constexpr int NWW = FW ? K : LK_SPLIT_IDLE_WAVES;   // W waves (fused warp): 64 columns each, one column per lane
+    static constexpr int NWW = FW ? K : 0;                    // W waves (fused warp): 64 columns each, one column per lane
     static constexpr int LAG = FW ? 2 : 0;           // pipeline steps the W role runs ahead of F
     static constexpr int PF = LK_SPLIT_PF;           // image rows in flight per F lane: a pipeline step is short, HBM latency is not
     static constexpr int NB = K;                     // B waves: 64 columns each
@@ -120,21 +104,13 @@ struct SplitCfg {
     static constexpr int SSTR = KH == 1 ? 64 : 72;
     static constexpr int PROD_D = KH * PSTR * 2;     // doubles per product plane
     static constexpr int SUMS_D = KH * SSTR * 2;     // doubles per sums plane
-#ifdef LK_SPLIT_WPE
-    static constexpr int WPE = LK_SPLIT_WPE;
-#else
     // waves per SIMD to compile for (8-wave blocks: 4 -> two blocks per CU; 10-wave blocks with the W role: 5 -> two blocks)
     static constexpr int WPE = FW ? 5 : ((K == 2 && WIN <= 21) ? 4 : (NF == 2 ? 3 : 1));   // nine waves: three on one SIMD
-#endif
-#ifdef LK_SPLIT_QSUM
-    static constexpr bool QSUM = LK_SPLIT_QSUM != 0;
-#else
     // F publishes the pair sums a + b (true) or S adds the raw pairs itself (false).  Up to 21 x 21 (two workgroups per CU)
     // F is the wave that paces a workgroup and S has slack: S adds (4K/L5/w21 28.4 -> 30.2 Gpx/s).  From 23 x 23 on (one
     // workgroup per CU, 16 LDS reads per row and field) the S waves' LDS reads are the longer pole: halving their bytes
     // wins (8K/L5/w31: level-0 LK 2.20 -> 2.08 ms; profiles/r02_j_qsum_ab.txt).
     static constexpr bool QSUM = WIN > 21;
-#endif
     static constexpr int UN = PF >= 4 ? PF / 2 : 2;  // unrolled F group in steps: even (LDS buffer parity) and PF rows (queue slots)
     static_assert(K == 2, "one F wave feeds 126 columns: S lanes own 2 columns (K = 4 ran one 11-wave block per CU: slower)");
     static_assert(PSTR >= NJP, "product half-planes must not overlap");
@@ -280,10 +256,8 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // trailing workgroups of the launch: the frame of width R just inside the image (lk_border_pixel above), one
         // pixel per thread.  They are dispatched last, into the slots the marching workgroups free as they finish, so
         // the frame costs neither a launch of its own nor the idle tail of one.
-#ifndef LK_SPLIT_ABL_NOFRAME   /* timing-only ablation build: the frame workgroups return at once (results are wrong) */
         const unsigned bb = blockIdx.x - a.nmain;
         lk_border_pixel<HAS_UP, FW>(a, WIN, (bb % a.nbb) * (unsigned)C::NT + threadIdx.x, (int)(bb / a.nbb));
-#endif
         return;
     }
     __shared__ __attribute__((aligned(16))) double s_prod[2][2][5][C::PROD_D];   // [step parity][row of the step][field]: (a, b) products of every column pair
@@ -295,35 +269,12 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     __shared__ __attribute__((aligned(16))) double s_c[FW ? 2 : 1][FW ? 2 : 1][FW ? 128 : 2];
 
     // logical wave (role order B, S, F) of the physical wave: the role -> SIMD placement is an A/B knob (-DLK_SPLIT_PERM=...)
-#ifdef LK_SPLIT_PERM
-    constexpr int kPerm[16] = {LK_SPLIT_PERM};
-    const int pw = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    int wv_ = 0;
-#pragma unroll
-    for (int q = 0; q < C::NW; ++q) wv_ = (pw == q) ? kPerm[q] : wv_;
-    const int wv = __builtin_amdgcn_readfirstlane(wv_);
-#elif defined(LK_SPLIT_ALT_BIT)
-    // Every other workgroup (bit LK_SPLIT_ALT_BIT of the workgroup index) swaps the roles of its last two waves: F, the
-    // wave with by far the longest instruction stream, then sits on SIMD 2 instead of SIMD 3 (waves are dealt to the
-    // SIMDs round-robin), so that the two workgroups that share a CU do not stack both F waves on one SIMD.
-    const int pw = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const bool alt = !FW && ((blockIdx.x >> LK_SPLIT_ALT_BIT) & 1u) != 0;
-    const int wv = (alt && pw >= C::NB + 4) ? 2 * C::NB + 9 - pw : pw;
-#else
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-#endif
     const int ltid = wv * 64 + ((int)threadIdx.x & 63);   // thread index in role order
-#ifdef LK_SPLIT_STAMPS
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
-#endif
     // 1-D grid, XCD-aware tile order (lk_kernels.h): workgroups are dealt round-robin over the 8 XCDs (private L2s), so
     // with the natural order the column blocks of one strip -- which share 2 HL halo columns -- and vertically adjacent
     // strips -- which share 2R apron rows -- land on different L2s and every shared line is fetched from HBM once per XCD
-#ifdef LK_SPLIT_NO_XCD
-    unsigned tile = blockIdx.x;
-#else
     unsigned tile = xcd_tile_id(blockIdx.x, a.nmain ? a.nmain : gridDim.x);
-#endif
     const int bx = tile % a.gx; tile /= a.gx;
     const int by = tile % a.gy;
     const int pair = tile / a.gy;
@@ -360,9 +311,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     [[maybe_unused]] auto up_srow_w = [&](int k) { const int Hc = H >> 1; return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };
     [[maybe_unused]] auto rot_row_off = [&](int t) { return max(up_srow_w(((ye0 + 2 * t) >> 1) + 1) - c_lo, 0); };   // row W-step t rotates in
 
-    if (!FW && wv >= C::NB + 5 + C::NF) {            // diagnostic idle waves (LK_SPLIT_IDLE_WAVES)
-        for (int k = 0; k < NS; ++k) __syncthreads();
-    } else if (FW && wv > C::NB + 5) {
+    if (FW && wv > C::NB + 5) {
       if constexpr (FW) {                            // (not even compiled for the unfused kernel)
         // =========================================================================================
         // W waves (fused warp, a9-a12): one column per lane -> the warped rows of both images, through LDS to F
@@ -429,12 +378,8 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
                 for (int im = 0; im < 2; ++im) {
                     const __amdgpu_buffer_rsrc_t rI = im ? rI2 : rI1;
                     double g0x, g0y, g1x, g1y;
-#ifdef LK_SPLIT_ABL_WNOLOAD   /* timing-only ablation build: no gathers (results are wrong) */
-                    g0x = g1y = (double)A.vo[e][im]; g0y = g1x = 1.0; (void)rI;
-#else
                     buf_ld2(rI, A.vo[e][im], 0, g0x, g0y);
                     buf_ld2(rI, A.vo[e][im], ipb, g1x, g1y);
-#endif
                     G[e][im][0].x = g0x; G[e][im][0].y = g0y; G[e][im][1].x = g1x; G[e][im][1].y = g1y;
                 }
         };
@@ -487,7 +432,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             cur = nxt;
             const double nu = s_c[WP ^ 1][0][g], nv = s_c[WP ^ 1][1][g];   // written by F in step t - 1: the row step t + 2 rotates in
             waddr(t + 2, nu, nv, nxt);
-            SP_BARRIER();
+            __syncthreads();
         };
         for (int t = 0; t < NS; t += 2) {                               // NS is even
             wstep(std::integral_constant<int, 0>{}, t);
@@ -578,7 +523,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             }(std::make_integer_sequence<int, 2>{});
             svc_publish(std::integral_constant<int, SP>{});             // the row W-step t + 3 rotates in (W reads it in step t + 1)
             svc_load(t + 4);
-            SP_BARRIER();
+            __syncthreads();
         };
         for (int t = 0; t < NS; t += 2) {
             fstepw(std::integral_constant<int, 0>{}, t);
@@ -636,27 +581,18 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             constexpr int QS = (2 * U + E) % PF;
             {
                 const int rn = img_row_off(yy0 + i + PF);
-#ifdef LK_SPLIT_ABL_NOLOAD
-                qa[QS][0] = qb[QS][0] = (double)rn; qa[QS][1] = qb[QS][1] = 1.0;
-#else
                 buf_ld2(rI1, vxc, rn, qa[QS][0], qb[QS][0]);
                 buf_ld2(rI2, vxc, rn, qa[QS][1], qb[QS][1]);
-#endif
             }
             const int yy = yy0 + i;
             const bool row_in = yy >= 0 && yy < H;
             if (C::NF == 1 || fe == E) {                     // (wave-uniform; no memory instruction inside)
-#ifdef LK_SPLIT_ABL_F   /* timing-only ablation build: no derivative arithmetic */
-            double fxa = ca[0], fya = ca[1], fxb = cb[0], fyb = cb[1];
-            const double fta = pl[0] + cl[0], ftb = pl[1] + cl[1] + pa[0] + pb[1];
-#else
             double fxa = f2d_x(pl[0], pa[0], cl[0], ca[0]) + f2d_x(pl[1], pa[1], cl[1], ca[1]);
             double fya = f2d_y(pl[0], pa[0], cl[0], ca[0]) + f2d_y(pl[1], pa[1], cl[1], ca[1]);
             const double fta = f2d_neg(pl[0], pa[0], cl[0], ca[0]) + f2d_pos(pl[1], pa[1], cl[1], ca[1]);
             double fxb = f2d_x(pa[0], pb[0], ca[0], cb[0]) + f2d_x(pa[1], pb[1], ca[1], cb[1]);
             double fyb = f2d_y(pa[0], pb[0], ca[0], cb[0]) + f2d_y(pa[1], pb[1], ca[1], cb[1]);
             const double ftb = f2d_neg(pa[0], pb[0], ca[0], cb[0]) + f2d_pos(pa[1], pb[1], ca[1], cb[1]);
-#endif
             if (!(row_in && all_col_in)) {                  // rows / columns outside the image contribute 0 (wave-uniform test)
                 const bool keep = row_in && col_in;
                 fxa = keep ? fxa : 0.0; fya = keep ? fya : 0.0;
@@ -668,12 +604,8 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             auto put = [&](auto fc, double xa_, double xb_) __attribute__((always_inline)) {
                 constexpr int FI = decltype(fc)::value;
                 o.x = xa_; o.y = xb_;
-#ifdef LK_SPLIT_ABL_NOFLDS
-                if (xa_ == 12345.678) s_q[SP][E][FI][p_chunk] = xa_ + xb_;
-#else
                 *reinterpret_cast<lk_d2 *>(&s_prod[SP][E][FI][2 * p_chunk]) = o;
                 if constexpr (C::QSUM) s_q[SP][E][FI][p_chunk] = xa_ + xb_;
-#endif
             };
             put(std::integral_constant<int, 0>{}, fxa * fxa, fxb * fxb);
             put(std::integral_constant<int, 1>{}, fya * fya, fyb * fyb);
@@ -690,16 +622,9 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             }
         };
         auto fstep = [&](auto spc, int st) __attribute__((always_inline)) {
-            SP_STAMP(t0);
             frow(spc, std::integral_constant<int, 0>{}, 2 * st);
             frow(spc, std::integral_constant<int, 1>{}, 2 * st + 1);
-#ifdef LK_SPLIT_STAMPS
-            asm volatile("" :: "v"(cl[0]), "v"(ca[0]), "v"(cb[0]), "v"(cl[1]), "v"(ca[1]), "v"(cb[1]));
-#endif
-            SP_STAMP(t1);
-            SP_BARRIER();
-            SP_STAMP(t2);
-            SP_ACC(0, t0, t1); SP_ACC(3, t1, t2);
+            __syncthreads();
         };
         for (int st = 0; st < NS; st += UN) {                // NS is a multiple of UN: no guards inside a group
             [&]<int... Us>(std::integer_sequence<int, Us...>) __attribute__((always_inline)) {
@@ -711,9 +636,6 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // =========================================================================================
         // B waves: one column per lane: window sums -> flow
         // =========================================================================================
-#ifdef LK_SPLIT_PRIO_B
-        __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_B);
-#endif
         const int t = ltid;                          // block column 0 .. TXC-1
         const int x = x0 + t;
         const int xc = min(max(x, 0), W - 1);
@@ -776,9 +698,6 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // unconditionally (see the file header); the two solves are independent and interleave.
         const int vo_lane = is_out ? vxo : (int)0x80000000;   // out of range: the store is dropped
         auto solve5 = [&](const double (&S)[5], double &u, double &v) __attribute__((always_inline)) {
-#ifdef LK_SPLIT_ABL_B   /* timing-only ablation build: no solve */
-            u = S[0] + S[2] + S[4]; v = S[1] + S[3]; return;
-#endif
             const double det = S[0] * S[1] - S[2] * S[2];
             const double un = S[2] * S[4] - S[1] * S[3];
             const double vn = S[3] * S[2] - S[0] * S[4];
@@ -807,11 +726,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             }
             double S0[5], S1[5];
 #pragma unroll
-#ifdef LK_SPLIT_ABL_NOBLDS
-            for (int f = 0; f < 5; ++f) { S0[f] = (double)(p + f); S1[f] = (double)(p - f) + 0.5; }
-#else
             for (int f = 0; f < 5; ++f) { S0[f] = s_sums[SPB][0][f][s_slot]; S1[f] = s_sums[SPB][1][f][s_slot]; }
-#endif
             double ue, ve, uo, vo;
             solve_row(y, S0, ue, ve);
             solve_row(y + 1, S1, uo, vo);
@@ -828,9 +743,6 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
                 hu[0] = pyrup_h1v(tp[P2][0], tp[P2][1], tp[P2][2], us);   // next coarse row, used from the next pair on
                 hv[0] = pyrup_h1v(tp[P2][3], tp[P2][4], tp[P2][5], us);
             }
-#ifdef LK_SPLIT_ABL_NOSTORE
-            if (ue + ve + uo + vo == 12345.678) buf_st(rU, vo_lane, sou, ue);
-#else
             // rows of the frame (wave-uniform test): out-of-range offset, the store is dropped
             const int voe = (y >= R && y < H - R) ? vo_lane : (int)0x80000000;
             const int voo = (y + 1 >= R && y + 1 < H - R) ? vo_lane : (int)0x80000000;
@@ -838,16 +750,11 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             buf_st(rV, voe, sov, ve);
             buf_st(rU, voo, sou + upb, uo);
             buf_st(rV, voo, sov + vpb, vo);
-#endif
             sou += 2 * upb; sov += 2 * vpb;
         };
         auto bstep = [&](auto pc2, int p) __attribute__((always_inline)) {
-            SP_STAMP(t0);
             bpair(pc2, p);
-            SP_STAMP(t1);
-            SP_BARRIER();
-            SP_STAMP(t2);
-            SP_ACC(1, t0, t1); SP_ACC(3, t1, t2);
+            __syncthreads();
         };
         for (int k = 0; k < R + 2 + C::LAG + (FW ? 1 : 0); ++k) __syncthreads();   // (FW: W / F prologue,) pipeline fill: no window sums yet
         const int npairs = nrows / 2;
@@ -900,25 +807,15 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
                 return;
             }
             const double *qq = &s_q[C::QSUM ? SPP : 0][C::QSUM ? E : 0][C::QSUM ? f : 0][C::QSUM ? PADJ + j : 0];
-#ifdef LK_SPLIT_ABL_NOSLDS
-#pragma unroll
-            for (int d = 0; d < NQ; ++d) r.q[d] = (double)(i + d);
-            r.sb = 1.0; r.sa = (double)(qq - pp);
-#else
 #pragma unroll
             for (int d = 0; d < NQ; ++d) r.q[d] = qq[d - QH];
             r.sb = pp[-2 * HS + 1];                          // b of pair j - HS
             r.sa = pp[2 * HS];                               // a of pair j + HS
-#endif
         };
         // horizontal windows + vertical van Herk step at static chunk position KC -> the K window sums of row i
         auto ssum = [&](auto kc, const SRow &r, double (&S)[K]) __attribute__((always_inline)) {
             constexpr int KC = decltype(kc)::value;
             double hs[K];
-#ifdef LK_SPLIT_ABL_S   /* timing-only ablation build: no horizontal sums */
-            hs[0] = r.sb + r.q[0]; hs[1] = r.sa + r.q[NQ - 1];
-            if constexpr (false)
-#endif
             if constexpr (RODD) {
                 const double shared = split_tree<0, NQ - 1>(r.q);
                 hs[0] = r.sb + shared;
@@ -945,9 +842,6 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // by which time every plane has been overwritten with real sums -- an unconditional store costs no test)
         auto sstore = [&](auto spc, auto ec, const double (&S)[K]) __attribute__((always_inline)) {
             constexpr int SPP = decltype(spc)::value, E = decltype(ec)::value;
-#ifdef LK_SPLIT_ABL_NOSWR
-            if (S[0] == 12345.678)
-#endif
             {
                 double *sp = &s_sums[SPP][E][f][0];
 #pragma unroll
@@ -965,30 +859,22 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             using SPc = std::integral_constant<int, T & 1>;
             using E0 = std::integral_constant<int, 0>;
             using E1 = std::integral_constant<int, 1>;
-            SP_STAMP(t0);
             SRow rA, rB;
             double SA[K], SB[K];
             constexpr bool BOTH = WIN <= (FW ? 11 : LK_SPLIT_BOTH_MAX);                 // bigger rings leave no registers for two rows of taps
             sload(SPc{}, E0{}, rA);
             if constexpr (BOTH) sload(SPc{}, E1{}, rB);
-#ifndef LK_SPLIT_NO_WAIT1
             __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
-#endif
             ssum(std::integral_constant<int, Q>{}, rA, SA);
             if constexpr (!BOTH) {
                 __builtin_amdgcn_sched_barrier(0);
                 sload(SPc{}, E1{}, rB);
-#ifndef LK_SPLIT_NO_WAIT1
                 __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
             }
             ssum(std::integral_constant<int, (Q + 1) % WIN>{}, rB, SB);
             sstore(SPc{}, E0{}, SA);
             sstore(SPc{}, E1{}, SB);
-            SP_STAMP(t1);
-            SP_BARRIER();
-            SP_STAMP(t2);
-            SP_ACC(0, t0, t1); SP_ACC(3, t1, t2);
+            __syncthreads();
         };
         for (int k = 0; k < 1 + C::LAG + (FW ? 1 : 0); ++k) __syncthreads();   // pipeline step 0 (FW: W / F prologue, 0..2): only the front end works
         // The van Herk chunks are anchored to ABSOLUTE image rows (chunk position of image row r = r mod WIN), so the
@@ -1008,14 +894,6 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         }
         for (int k = nsw + 1 + C::LAG; k < NS; ++k) __syncthreads(); // remaining steps: only the back end works / idle tail
     }
-#ifdef LK_SPLIT_STAMPS
-    if (a.dbg && (threadIdx.x & 63) == 0) {
-        const unsigned wid = blockIdx.x * C::NW + wv;
-        for (int k = 0; k < 6; ++k) a.dbg[wid * 8 + k] = seg[k];
-        a.dbg[wid * 8 + 6] = NS;
-        a.dbg[wid * 8 + 7] = wv;
-    }
-#endif
 }
 
 }  // namespace lk

@@ -285,23 +285,6 @@ int launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStr
     }
     a.th = th;
     dim3 grid(gx, (a.H + th - 1) / th, pairs);
-#ifdef LK3_STAMPS
-    {   // diagnostic build: dump the stamps of the largest launch to $LKFLOW_STAMPS_OUT after the run
-        static unsigned long long *dbuf = nullptr; static size_t dn = 0;
-        const size_t nw = (size_t)grid.x * grid.y * grid.z * (TX / 64);
-        if (has_up && nw * 8 > dn) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc((void **)&dbuf, nw * 64); dn = nw * 8; }
-        a.dbg = (has_up && nw * 8 == dn) ? dbuf : nullptr;
-        if (a.dbg && getenv("LKFLOW_STAMPS_OUT")) {
-            hipLaunchKernelGGL((lk::lk_march3_kernel<WIN, TX, true>), grid, dim3(TX), 0, s, a);
-            (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> h(dn);
-            (void)hipMemcpy(h.data(), dbuf, dn * 8, hipMemcpyDeviceToHost);
-            FILE *f = fopen(getenv("LKFLOW_STAMPS_OUT"), "wb");
-            if (f) { fwrite(h.data(), 8, dn, f); fclose(f); }
-            return LKFLOW_OK;
-        }
-    }
-#endif
     if (has_up)
         hipLaunchKernelGGL((lk::lk_march3_kernel<WIN, TX, true>), grid, dim3(TX), 0, s, a);
     else
@@ -313,7 +296,8 @@ int launch_lk3_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStr
 // by lk_border_kernel and by nobody else, so it does not have to wait for the main LK kernel: it is forked onto the
 // context's side stream (both kernels depend on the warp before them only) and joined after the main launch.  The
 // fork / join is a pair of events, so it is captured into a HIP graph like any other dependency.
-// LKFLOW_BORDER_SIDE=0 (debug knob, A/B): same stream, in front of the main kernel.
+// Only the -DLKFLOW_DEBUG_KNOBS build can take this path (LKFLOW_BORDER_MERGED=0 LKFLOW_BORDER_SIDE=1, A/B): the shipped
+// library writes the frame in trailing workgroups of the main launch.
 struct BorderFork {
     lkflow_ctx *ctx; hipStream_t s, bs;
     BorderFork(lkflow_ctx *c, hipStream_t st) : ctx(c), s(st), bs(st)
@@ -368,23 +352,6 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
     a.gx = gx; a.gy = (a.H + th - 1) / th;
     if ((long long)a.gx * a.gy * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
     dim3 grid((unsigned)(a.gx * a.gy * pairs));      // 1-D: the kernel orders the tiles per XCD
-#ifdef LK_SPLIT_STAMPS
-    {   // diagnostic build: dump the stamps of the largest launch to $LKFLOW_STAMPS_OUT after the run
-        static unsigned long long *dbuf = nullptr; static size_t dn = 0;
-        const size_t nw = (size_t)grid.x * grid.y * grid.z * C::NW;
-        if (has_up && nw * 8 > dn) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc((void **)&dbuf, nw * 64); dn = nw * 8; }
-        a.dbg = (has_up && nw * 8 == dn) ? dbuf : nullptr;
-        if (a.dbg && getenv("LKFLOW_STAMPS_OUT")) {
-            hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true>), grid, dim3(C::NT), 0, s, a);
-            (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> h(dn);
-            (void)hipMemcpy(h.data(), dbuf, dn * 8, hipMemcpyDeviceToHost);
-            FILE *f = fopen(getenv("LKFLOW_STAMPS_OUT"), "wb");
-            if (f) { fwrite(h.data(), 8, dn, f); fclose(f); }
-            return LKFLOW_OK;
-        }
-    }
-#endif
     // the frame of clipped-window pixels (SerialPyr.cpp:94-95) and the outermost ring: frame pixels per pair
     const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
     const long long nfp = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);

@@ -47,3 +47,28 @@ def test_header_host_tail_and_mat_standin(tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "header_tail_check.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def _build_opencv_branch(tmp_path):
+    exe = str(tmp_path / "opencv_branch_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "cpp", "fake_opencv"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "opencv_branch_check.cpp"),
+                           "-o", exe, "-L", PKG, "-llkflow", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cv_mat_branch_of_the_header_compiles(tmp_path, lkflow):
+    """include/lkflow.hpp with `Mat = cv::Mat` (LKFLOW_HAVE_OPENCV): OpenCV is absent from the image, so the branch is
+    compiled against tests/cpp/fake_opencv (a stand-in with the cv::Mat members the reference's call sites use)."""
+    lkflow.lib()
+    exe = _build_opencv_branch(tmp_path)
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
+def test_cv_mat_call_site_with_unequal_steps(tmp_path):
+    """The reference's call site (ParallelVideoPyr.cpp:822-832) on cv::Mat arguments whose row steps differ (padded
+    matrices): same flow, same in-place overwrite of the inputs as with continuous matrices; a size mismatch throws."""
+    exe = _build_opencv_branch(tmp_path)
+    r = subprocess.run([exe, "run"], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
