@@ -61,7 +61,9 @@ const char *lkflow_version(void);
 /* Diagnostics / measurement: the name (as rocprofv3 prints it) of the LK kernel the library launches for one
  * pyramid level of rows x cols with window `win`; has_up = the level is below the coarsest (it adds the
  * up-sampled coarse flow), fused_ok = the call does not need the level's warped images in memory
- * (i.e. not level 0 of a LKFLOW_MUTATE_INPUTS call).  bench.py labels its roofline with it. */
+ * (i.e. not level 0 of a LKFLOW_MUTATE_INPUTS call).  The answer is for a context with DEFAULT options (LKFLOW_OPT_IMPL,
+ * LKFLOW_OPT_FUSE_WARP and LKFLOW_OPT_LK_BATCH select other kernels); the shipped library has no other knob that could
+ * change it.  bench.py labels its roofline with it. */
 int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok, char *buf, size_t n);
 
 /* One context per GPU and caller thread: owns the device workspace (pyramids, per-level flow). */

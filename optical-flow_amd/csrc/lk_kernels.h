@@ -45,6 +45,9 @@ __device__ __forceinline__ unsigned xcd_tile_id(unsigned lin, unsigned n)
 // five horizontal results in registers while the wave marches down its strip of output rows.
 // No LDS, no barriers, ~30 VGPRs.  Block = 4 waves side by side (248 output columns).
 // ------------------------------------------------------------------------------------------------
+#ifndef LK_PD_LOAD_AUX
+#define LK_PD_LOAD_AUX 0    /* cache policy of pyrDown's source loads (2 = nt: A/B in profiles/r03_*) */
+#endif
 struct PyrDownArgs {
     CPlanes src;
     Planes dst;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
         const int so = (r101(sy, H) - row_lo) * pitchb;     // row index is wave-uniform
         if (vec) {
             typedef unsigned int lk_u4 __attribute__((ext_vector_type(4)));
-            const lk_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rS, c0 * 8, so, 0);
+            const lk_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rS, c0 * 8, so, LK_PD_LOAD_AUX);
             cx = __hiloint2double((int)v.y, (int)v.x); cy = __hiloint2double((int)v.w, (int)v.z);
         } else {
             cx = buf_ld(rS, r0c * 8, so); cy = buf_ld(rS, r1c * 8, so);

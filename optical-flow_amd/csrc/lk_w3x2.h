@@ -21,9 +21,12 @@ namespace lk {
 
 typedef unsigned int lk_u4 __attribute__((ext_vector_type(4)));
 
+#ifndef LK_IMG_LOAD_AUX
+#define LK_IMG_LOAD_AUX 0   /* cache policy of the LK kernels' 16-byte image loads (2 = nt: A/B in profiles/r03_*) */
+#endif
 __device__ __forceinline__ void buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int soff, double &x, double &y)
 {
-    const lk_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const lk_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, LK_IMG_LOAD_AUX);
     x = __hiloint2double((int)v.y, (int)v.x);
     y = __hiloint2double((int)v.w, (int)v.z);
 }

@@ -382,7 +382,7 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
 // Warp fused into the wave-specialised kernel (lk_split.h, W role): a.i1 / a.i2 are the UN-warped level images,
 // the warped planes never reach memory.  LK_NOT_TAKEN: shape not taken (the caller runs warp + LK).
 template <int WIN, int K>
-int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
+int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s, int level)
 {
     using C = lk::SplitCfg<WIN, K, true>;
     if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return LK_NOT_TAKEN;
@@ -405,6 +405,7 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
     a.gx = gx; a.gy = (a.H + th - 1) / th;
     if ((long long)a.gx * a.gy * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
     a.nmain = 0; a.nbb = 0;
+    ProfScope ps(ctx, LKFLOW_STAGE_LK, level, s);    // (opened only once the shape is taken: a fallback leaves no empty record)
     BorderFork bf(ctx, s);
     {   // the frame of clipped-window pixels and the outermost ring (its warped taps are made on the fly)
         const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
@@ -421,10 +422,10 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
 #define LKFLOW_SPLIT_FUSED_MAX_WIN 15                // bigger rings do not fit the 96 VGPRs of a 10-wave block pair
 bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H);
 
-int launch_splitw(lkflow_ctx *ctx, const lk::LKArgs &a, int pairs, int win, hipStream_t s)
+int launch_splitw(lkflow_ctx *ctx, const lk::LKArgs &a, int pairs, int win, hipStream_t s, int level)
 {
     switch (win) {
-#define SP_CASE(WN) case WN: return launch_splitw_win<WN, 2>(ctx, a, pairs, s);
+#define SP_CASE(WN) case WN: return launch_splitw_win<WN, 2>(ctx, a, pairs, s, level);
 #ifdef LKFLOW_FAST_BUILD
         SP_CASE(15)
 #else
@@ -992,8 +993,7 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
             lk::LKArgs f = a;
             f.i1 = pyr(l, 0); f.i2 = pyr(l, 1);
             f.cu = as_c(flow_w(l + 1, 0)); f.cv = as_c(flow_w(l + 1, 1));
-            ProfScope ps(ctx, LKFLOW_STAGE_LK, l, s);
-            rc = launch_splitw(ctx, f, P, win, s);
+            rc = launch_splitw(ctx, f, P, win, s, l);
             if (rc == LKFLOW_OK) continue;
             if (rc != LK_NOT_TAKEN) return rc;                   // not taken: warp + LK below
         }
