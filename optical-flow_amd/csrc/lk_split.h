@@ -58,6 +58,15 @@
 #ifndef LK_SPLIT_BOTH_MAX
 #define LK_SPLIT_BOTH_MAX 15   /* widest window whose S waves issue the LDS reads of both rows of a step up front */
 #endif
+#ifndef LK_SPLIT_QDPP
+#define LK_SPLIT_QDPP 1  /* S waves up to 21 x 21: neighbours' pair sums by DPP wave shifts instead of LDS reads (A/B: profiles/r03_c_*) */
+#endif
+#ifndef LK_SPLIT_TWO_WG_MAX
+#define LK_SPLIT_TWO_WG_MAX 27   /* widest window compiled for 128 VGPRs = two 8-wave workgroups per CU */
+#endif
+#ifndef LK_SPLIT_QSUM_ABOVE
+#define LK_SPLIT_QSUM_ABOVE 21   /* windows above this: F publishes the pair sums (SplitCfg::QSUM) */
+#endif
 #ifndef LK_SPLIT_TD
 #define LK_SPLIT_TD 2    /* even: row pairs of coarse taps a B lane keeps in flight (4 spills at 15x15 and is slower) */
 #endif
@@ -89,7 +98,7 @@ struct SplitCfg {
     // gain 4-5 % (3840 x 2160 / L5, level-0 LK 1.00 -> 0.95 ms at 23 x 23, 1.03 -> 0.995 at 27 x 27); the 29 x 29 and
     // 31 x 31 rings would spill (31 x 31: 68 bytes, 8K/L5/w31 level-0 LK 2.02 -> 2.45 ms) and keep one F wave
     // (profiles/r02_j_bigwin_knobs_ab.txt).
-    static constexpr int NF = (!FW && WIN >= LK_SPLIT_NF2_MIN && WIN <= LK_SPLIT_NF2_MAX) ? 2 : 1;
+    static constexpr int NF = (!FW && WIN >= LK_SPLIT_NF2_MIN && WIN <= LK_SPLIT_NF2_MAX && WIN > LK_SPLIT_TWO_WG_MAX) ? 2 : 1;
     static constexpr int TXC = 64 * K - 2;           // columns per block with products
     static constexpr int HL = R + (R & 1);           // halo columns on each side (even: a lane's column pair is 16-byte aligned)
     static constexpr int XO = TXC - 2 * HL;          // output columns per block
@@ -105,17 +114,31 @@ struct SplitCfg {
     static constexpr int PROD_D = KH * PSTR * 2;     // doubles per product plane
     static constexpr int SUMS_D = KH * SSTR * 2;     // doubles per sums plane
     // waves per SIMD to compile for (8-wave blocks: 4 -> two blocks per CU; 10-wave blocks with the W role: 5 -> two blocks)
-    static constexpr int WPE = FW ? 5 : ((K == 2 && WIN <= 21) ? 4 : (NF == 2 ? 3 : 1));   // nine waves: three on one SIMD
+    static constexpr int WPE = FW ? 5 : ((K == 2 && WIN <= LK_SPLIT_TWO_WG_MAX) ? 4 : (NF == 2 ? 3 : 1));   // nine waves: three on one SIMD
     // F publishes the pair sums a + b (true) or S adds the raw pairs itself (false).  Up to 21 x 21 (two workgroups per CU)
     // F is the wave that paces a workgroup and S has slack: S adds (4K/L5/w21 28.4 -> 30.2 Gpx/s).  From 23 x 23 on (one
     // workgroup per CU, 16 LDS reads per row and field) the S waves' LDS reads are the longer pole: halving their bytes
     // wins (8K/L5/w31: level-0 LK 2.20 -> 2.08 ms; profiles/r02_j_qsum_ab.txt).
-    static constexpr bool QSUM = WIN > 21;
+    static constexpr bool QSUM = WIN > LK_SPLIT_QSUM_ABOVE && WIN > LK_SPLIT_TWO_WG_MAX;
     static constexpr int UN = PF >= 4 ? PF / 2 : 2;  // unrolled F group in steps: even (LDS buffer parity) and PF rows (queue slots)
     static_assert(K == 2, "one F wave feeds 126 columns: S lanes own 2 columns (K = 4 ran one 11-wave block per CU: slower)");
     static_assert(PSTR >= NJP, "product half-planes must not overlap");
     static_assert(PF == 2 || (PF % 4 == 0 && PF <= 16), "static queue slots: two rows per step, an even number of steps per group");
 };
+
+// lane l <- lane l - 1 / lane l + 1 of the wave (edge lanes: 0), without the zero-initialised "old" operand of dpp_wave_shr1
+__device__ __forceinline__ double dpp_from_left(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_right(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 
 // tree sum of v[LO..HI] (compile-time bounds)
 template <int LO, int HI, typename A>
@@ -785,6 +808,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         constexpr int NQ = 2 * QH + 1;
         static_assert(K == 2 && HS <= PADJ, "pad lanes cover the taps");
         struct SRow { double q[NQ], sb, sa; };
+        constexpr bool STREAMED = LK_SPLIT_QDPP && !C::QSUM && WIN > 21;   // (see sload)
         double ring[WIN][K], pre[K];
 #pragma unroll
         for (int q = 0; q < WIN; ++q)
@@ -796,6 +820,39 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         auto sload = [&](auto spc, auto ec, SRow &r) __attribute__((always_inline)) {
             constexpr int SPP = decltype(spc)::value, E = decltype(ec)::value;   // LDS plane (step parity), row of the step
             const double *pp = &s_prod[SPP][E][f][2 * (PADJ + j)];
+            if constexpr (!C::QSUM && LK_SPLIT_QDPP) {
+                // The lane reads ONLY its own pair and forms its pair sum; the neighbours' pair sums -- the same values, each
+                // formed once by the lane that owns the pair -- arrive by DPP wave shifts, one lane per shift.  Against NQ
+                // sixteen-byte LDS reads and NQ additions per row: 1 read, 1 addition and 2 (NQ - 1) 32-bit moves; the LDS pipe
+                // is this kernel's busiest unit.  Same values in the same tree: bit-identical.  Lanes within
+                // QH of a wave edge receive zeros -- they are halo lanes, never output lanes (HL / 2 >= QH).
+                const lk_d2 c2 = *reinterpret_cast<const lk_d2 *>(pp);
+                const double q0 = c2.x + c2.y;
+                double l = q0, g = q0;
+                if constexpr (STREAMED) {
+                    // windows above 21 x 21: the shared part of the two windows is accumulated as the pair sums arrive (centre
+                    // outwards, left before right) instead of being kept for a tree: 3 live values instead of NQ -- the 2 NQ
+                    // registers this frees are what lets 23 x 23 run two workgroups per CU (ring 88 + the rest <= 128 VGPRs)
+                    double acc = q0;
+#pragma unroll
+                    for (int d = 1; d <= QH; ++d) {
+                        l = dpp_from_left(l); g = dpp_from_right(g);
+                        if (RODD || d < QH) acc = (acc + l) + g;
+                        else { r.q[0] = l; r.q[NQ - 1] = g; }        // R even: the outermost pair sums belong to one window each
+                    }
+                    r.q[QH] = acc;
+                } else {
+                    r.q[QH] = q0;
+#pragma unroll
+                    for (int d = 1; d <= QH; ++d) {
+                        l = dpp_from_left(l); r.q[QH - d] = l;       // q of pair j - d
+                        g = dpp_from_right(g); r.q[QH + d] = g;      // q of pair j + d
+                    }
+                }
+                r.sb = pp[-2 * HS + 1];
+                r.sa = pp[2 * HS];
+                return;
+            }
             if constexpr (!C::QSUM) {                        // the pairs themselves (16-byte reads), summed here: F, the one wave
 #pragma unroll                                               // that feeds the block, has the longest instruction stream
                 for (int d = 0; d < NQ; ++d) {
@@ -817,11 +874,11 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             constexpr int KC = decltype(kc)::value;
             double hs[K];
             if constexpr (RODD) {
-                const double shared = split_tree<0, NQ - 1>(r.q);
+                const double shared = STREAMED ? r.q[QH] : split_tree<0, NQ - 1>(r.q);
                 hs[0] = r.sb + shared;
                 hs[1] = shared + r.sa;
             } else {
-                const double shared = split_tree<1, NQ - 2>(r.q);
+                const double shared = STREAMED ? r.q[QH] : split_tree<1, NQ - 2>(r.q);
                 hs[0] = (r.q[0] + shared) + r.sa;
                 hs[1] = (r.sb + shared) + r.q[NQ - 1];
             }

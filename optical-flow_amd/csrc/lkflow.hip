@@ -461,7 +461,7 @@ int launch_split(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, i
 #endif
         SP_CASE(15, LK_SPLIT_K15) SP_CASE(21, 2) SP_CASE(31, 2)
 #ifdef LKFLOW_FAST_WINS_EXTRA   /* experiments on the windows between */
-        SP_CASE(23, 2) SP_CASE(27, 2)
+        SP_CASE(23, 2) SP_CASE(25, 2) SP_CASE(27, 2) SP_CASE(29, 2)
 #endif
 #else
         SP_CASE(5, 2) SP_CASE(7, 2) SP_CASE(9, 2) SP_CASE(11, 2) SP_CASE(13, 2) SP_CASE(15, 2)
@@ -583,7 +583,7 @@ int launch_lk3(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, int
 #ifdef LKFLOW_FAST_BUILD   /* A/B experiment builds: only the windows the goldens / headline use */
         LK_CASE(3) LK_CASE(5) LK_CASE(9) LK_CASE(13) LK_CASE(15) LK_CASE(21)
 #ifdef LKFLOW_FAST_WINS_EXTRA
-        LK_CASE(23) LK_CASE(27)
+        LK_CASE(23) LK_CASE(25) LK_CASE(27) LK_CASE(29) LK_CASE(31)
 #endif
 #else
         LK_CASE(3) LK_CASE(5) LK_CASE(7) LK_CASE(9) LK_CASE(11) LK_CASE(13) LK_CASE(15) LK_CASE(17)
