@@ -14,11 +14,13 @@
 //     five products of both columns (one ds_write_b128 per field).  Runs at raised wave priority: it is the one
 //     wave that feeds the block from memory, and it has the longest instruction stream of the three roles.
 //   * 5 "S" waves, one FIELD each, two adjacent columns per lane: both horizontal windows of the pair are the
-//     R pair sums they share plus one single product each (R 16-byte LDS reads of column pairs, summed here,
-//     + 2 eight-byte reads, 2R + 1 additions per row at odd R; -DLK_SPLIT_QSUM=1: F publishes the pair sums
-//     instead), then the vertical van Herk / Gil-Werman ring for the two columns in registers ((WIN-1) x 2 x 2 = 56
-//     VGPRs at 15 x 15), chunks anchored to absolute image rows (results do not depend on the strip height);
-//     the two window sums go back through LDS (one 16-byte store).
+//     R pair sums they share plus one single product each.  Round 3: a lane reads only its OWN pair (one 16-byte LDS
+//     read), forms its pair sum and receives the neighbours' by DPP wave shifts (LK_SPLIT_QDPP; bit-identical to the
+//     round-2 form with R 16-byte reads and R additions per row; 29 x 29 and 31 x 31 -- one workgroup per CU -- read the
+//     pair sums F publishes instead, SplitCfg::QSUM); + 2 eight-byte reads of the single products; then the vertical
+//     van Herk / Gil-Werman ring for the two columns in registers ((WIN-1) x 2 x 2 = 56 VGPRs at 15 x 15), chunks
+//     anchored to absolute image rows (results do not depend on the strip height); the two window sums go back through
+//     LDS (one 16-byte store).
 //   * 2 "B" (back) waves, one column per lane: the five window sums of a row come back from LDS (one
 //     ds_read_b64 per field) -> 2 x 2 solve with true fp64 divisions, /0 -> 0, "+= pyrUp(coarse flow)" from
 //     register-carried coarse rows (taps fetched one step ahead), streaming store.  The frame of width R just inside
@@ -32,14 +34,15 @@
 // issued unconditionally (clamped rows; a store that must not happen gets an out-of-range buffer offset, which
 // the hardware drops): hipcc's s_waitcnt counting gives up on loads or stores under a condition and then drains
 // vmcnt(0) at every use, which serialised a step behind its own prefetch (F) and behind its own stores (B).
-// <= 128 VGPRs up to 21 x 21: four waves per SIMD = TWO blocks per CU, whose phases interleave (one block per CU
-// marches in lock-step: every wave reads LDS, computes and writes at the same time).  1-D grid, XCD-aware tile
+// <= 128 VGPRs up to 27 x 27 (round 3; 21 x 21 before the DPP pair sums freed the S waves' read buffers): four waves per
+// SIMD = TWO blocks per CU, whose phases interleave (one block per CU marches in lock-step: every wave reads LDS,
+// computes and writes at the same time).  1-D grid, XCD-aware tile
 // order (column blocks of a strip and vertically adjacent strips share halo lines through one L2).
 //
 // FW = true (opt-in, LKFLOW_OPT_FUSE_WARP): two more "W" waves per block run the warp of the level (a9-a12: cv::pyrUp of
 // the coarse flow, float map, fixed-point remap of both UN-warped images) and hand the rows to F through LDS, so the warped
 // planes never reach memory; F then serves W the filtered coarse rows.  Bit-identical to warp_kernel + this kernel, but
-// slower on MI355X: a 10-wave block does not share a CU with a second one (DESIGN.md section 8.3), so it is not the default.
+// slower on MI355X: a 10-wave block does not share a CU with a second one (DESIGN.md section 4.4), so it is not the default.
 //
 // Only additions in the window sums (flat regions give exactly 0 like the reference); same products, solve and pyrUp
 // expressions as lk_march3.h.  Host-checked: W and H even, H > R + PF + 1, even strip height (a step's row pair is an
