@@ -158,13 +158,18 @@ __global__ __launch_bounds__(512, 4) void lk_batch_kernel(LKArgs a)
                 }
         }
         if constexpr (FW) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int yw = e ? yw1 : yw0;
-                const float hx = (float)uu[e] / 2, hy = (float)vv[e] / 2;   // map build (ParallelVideoPyr.cpp:674-678), float32
-                w1[e] = remap_bilinear(I1, ip, H, W, (float)t.xw + hx, (float)yw + hy);
-                w2[e] = remap_bilinear(I2, ip, H, W, (float)t.xw - hx, (float)yw - hy);
-            }
+            // map build (ParallelVideoPyr.cpp:674-678) in float32; all eight gathers of the unit unconditionally and up front
+            // (lk_device.h remap_taps / remap_blend: remap_bilinear's arithmetic without its conditional loads)
+            const float hx0 = (float)uu[0] / 2, hy0 = (float)vv[0] / 2, hx1 = (float)uu[1] / 2, hy1 = (float)vv[1] / 2;
+            const float xf = (float)t.xw, yf0 = (float)yw0, yf1 = (float)yw1;
+            const RemapTaps ta0 = remap_taps(ip, H, W, xf + hx0, yf0 + hy0), tb0 = remap_taps(ip, H, W, xf - hx0, yf0 - hy0);
+            const RemapTaps ta1 = remap_taps(ip, H, W, xf + hx1, yf1 + hy1), tb1 = remap_taps(ip, H, W, xf - hx1, yf1 - hy1);
+            const lk_d2u g0 = *reinterpret_cast<const lk_d2u *>(I1 + ta0.off), g1 = *reinterpret_cast<const lk_d2u *>(I1 + ta0.off + ip);
+            const lk_d2u g2 = *reinterpret_cast<const lk_d2u *>(I2 + tb0.off), g3 = *reinterpret_cast<const lk_d2u *>(I2 + tb0.off + ip);
+            const lk_d2u g4 = *reinterpret_cast<const lk_d2u *>(I1 + ta1.off), g5 = *reinterpret_cast<const lk_d2u *>(I1 + ta1.off + ip);
+            const lk_d2u g6 = *reinterpret_cast<const lk_d2u *>(I2 + tb1.off), g7 = *reinterpret_cast<const lk_d2u *>(I2 + tb1.off + ip);
+            w1[0] = remap_blend(ta0, g0, g1, H, W); w2[0] = remap_blend(tb0, g2, g3, H, W);
+            w1[1] = remap_blend(ta1, g4, g5, H, W); w2[1] = remap_blend(tb1, g6, g7, H, W);
         } else {
             w1[0] = I1[(long long)yw0 * ip + t.xw]; w2[0] = I2[(long long)yw0 * ip + t.xw];
             w1[1] = I1[(long long)yw1 * ip + t.xw]; w2[1] = I2[(long long)yw1 * ip + t.xw];

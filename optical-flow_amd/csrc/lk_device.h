@@ -166,6 +166,50 @@ __device__ __forceinline__ double remap_bilinear(const double *src, int pitch, i
     return v0 * (double)w0 + v1 * (double)w1 + v2 * (double)w2 + v3 * (double)w3;
 }
 
+// The same sample for TWO independent (image, coordinate) pairs with every gather issued UNCONDITIONALLY and up front: the
+// taps are fetched from addresses clamped into the image (H, W >= 2) and the ones that fall outside are zeroed afterwards
+// (BORDER_CONSTANT 0) -- no load sits under a condition, so hipcc's vmcnt counting stays exact and the four 16-byte
+// gathers fly together (remap_bilinear's conditional loads make it drain vmcnt(0) in front of each one: four serial memory
+// round trips per marched row in a kernel that has only two waves per SIMD to hide them).  Same fixed-point arithmetic,
+// same blend expression: bit-identical to remap_bilinear().
+struct RemapTaps { int sx, sy; int off; };
+__device__ __forceinline__ RemapTaps remap_taps(int pitch, int H, int W, float mx, float my)
+{
+    RemapTaps t;
+    t.sx = cv_round_f(mx * 32.0f);
+    t.sy = cv_round_f(my * 32.0f);
+    const int ixc = min(max(sat_short(t.sx >> 5), 0), W - 2), iyc = min(max(sat_short(t.sy >> 5), 0), H - 2);
+    t.off = iyc * pitch + ixc;
+    return t;
+}
+typedef double lk_d2u __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ double remap_blend(const RemapTaps &t, lk_d2u top, lk_d2u bot, int H, int W)
+{
+    const int ix = sat_short(t.sx >> 5), iy = sat_short(t.sy >> 5);
+    const int dx = ix - min(max(ix, 0), W - 2), dy = iy - min(max(iy, 0), H - 2);
+    const float a = (float)(t.sx & 31) * (1.0f / 32), b = (float)(t.sy & 31) * (1.0f / 32);
+    const float w0 = (1.0f - b) * (1.0f - a), w1 = (1.0f - b) * a, w2 = b * (1.0f - a), w3 = b * a;
+    if ((dx | dy) != 0) {                                    // some tap of this lane leaves the image (no memory instruction inside)
+        const lk_d2u z = {0.0, 0.0};
+        const lk_d2u t0 = top, t1 = bot;
+        top = dy == 0 ? t0 : (dy == 1 ? t1 : z);
+        bot = dy == 0 ? t1 : (dy == -1 ? t0 : z);
+        const lk_d2u a0 = top, a1 = bot;
+        top.x = dx == 0 ? a0.x : (dx == 1 ? a0.y : 0.0); top.y = dx == 0 ? a0.y : (dx == -1 ? a0.x : 0.0);
+        bot.x = dx == 0 ? a1.x : (dx == 1 ? a1.y : 0.0); bot.y = dx == 0 ? a1.y : (dx == -1 ? a1.x : 0.0);
+    }
+    return top.x * (double)w0 + top.y * (double)w1 + bot.x * (double)w2 + bot.y * (double)w3;
+}
+__device__ __forceinline__ void remap_bilinear_x2(const double *srcA, const double *srcB, int pitch, int H, int W, float mxA,
+                                                  float myA, float mxB, float myB, double &outA, double &outB)
+{
+    const RemapTaps ta = remap_taps(pitch, H, W, mxA, myA), tb = remap_taps(pitch, H, W, mxB, myB);
+    const lk_d2u a0 = *reinterpret_cast<const lk_d2u *>(srcA + ta.off), a1 = *reinterpret_cast<const lk_d2u *>(srcA + ta.off + pitch);
+    const lk_d2u b0 = *reinterpret_cast<const lk_d2u *>(srcB + tb.off), b1 = *reinterpret_cast<const lk_d2u *>(srcB + tb.off + pitch);
+    outA = remap_blend(ta, a0, a1, H, W);
+    outB = remap_blend(tb, b0, b1, H, W);
+}
+
 // Raw buffer access (gfx9 V#: stride 0, offset = VGPR byte offset + SGPR byte offset, range-checked
 // against num_records).  The per-thread column offset is loop-invariant and the row offset is
 // wave-uniform, so a row access costs NO vector ALU address arithmetic.

@@ -174,6 +174,9 @@ struct WarpArgs {
     int th;           // rows per block (even)
 };
 
+#ifndef LK_WARP_UNCOND
+#define LK_WARP_UNCOND 1    /* warp_kernel: all eight gathers of a row pair unconditionally and up front (A/B: profiles/r03_e_*) */
+#endif
 #ifndef LK_WARP_WAVES
 #define LK_WARP_WAVES 1
 #endif
@@ -235,10 +238,22 @@ __global__ __launch_bounds__(256, LK_WARP_WAVES) void warp_kernel(WarpArgs a)
         const float yf0 = (float)y, yf1 = (float)(y + 1);
         const int so1 = (y - y0) * op1b, so2 = (y - y0) * op2b;
         // all four gathers in flight before the first store (H is even: row y+1 exists)
+#if LK_WARP_UNCOND
+        // all eight gathers of the row pair unconditionally and up front (lk_device.h remap_taps / remap_blend: bit-identical)
+        const RemapTaps ta0 = remap_taps(ip, H, W, xf + hx0, yf0 + hy0), tb0 = remap_taps(ip, H, W, xf - hx0, yf0 - hy0);
+        const RemapTaps ta1 = remap_taps(ip, H, W, xf + hx1, yf1 + hy1), tb1 = remap_taps(ip, H, W, xf - hx1, yf1 - hy1);
+        const lk_d2u g0 = *reinterpret_cast<const lk_d2u *>(I1 + ta0.off), g1 = *reinterpret_cast<const lk_d2u *>(I1 + ta0.off + ip);
+        const lk_d2u g2 = *reinterpret_cast<const lk_d2u *>(I2 + tb0.off), g3 = *reinterpret_cast<const lk_d2u *>(I2 + tb0.off + ip);
+        const lk_d2u g4 = *reinterpret_cast<const lk_d2u *>(I1 + ta1.off), g5 = *reinterpret_cast<const lk_d2u *>(I1 + ta1.off + ip);
+        const lk_d2u g6 = *reinterpret_cast<const lk_d2u *>(I2 + tb1.off), g7 = *reinterpret_cast<const lk_d2u *>(I2 + tb1.off + ip);
+        const double a0 = remap_blend(ta0, g0, g1, H, W), b0 = remap_blend(tb0, g2, g3, H, W);
+        const double a1 = remap_blend(ta1, g4, g5, H, W), b1 = remap_blend(tb1, g6, g7, H, W);
+#else
         const double a0 = remap_bilinear(I1, ip, H, W, xf + hx0, yf0 + hy0);
         const double b0 = remap_bilinear(I2, ip, H, W, xf - hx0, yf0 - hy0);
         const double a1 = remap_bilinear(I1, ip, H, W, xf + hx1, yf1 + hy1);
         const double b1 = remap_bilinear(I2, ip, H, W, xf - hx1, yf1 - hy1);
+#endif
         buf_st(rO1, x8, so1, a0); buf_st(rO2, x8, so2, b0);
         buf_st(rO1, x8, so1 + op1b, a1); buf_st(rO2, x8, so2 + op2b, b1);
         hu0 = hu1; hu1 = hu2; hv0 = hv1; hv1 = hv2;

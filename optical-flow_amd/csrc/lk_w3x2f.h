@@ -13,6 +13,10 @@
 #pragma once
 #include "lk_w3x2.h"
 
+#ifndef LK_W3F_UNCOND
+#define LK_W3F_UNCOND 2     /* fused 3 x 3 kernel: 0 = remap_bilinear (conditional gathers), 1 = unconditional, two at a time, 2 = all eight of a row at once (A/B: profiles/r03_e_*) */
+#endif
+
 namespace lk {
 
 __global__ __launch_bounds__(64, 2) void lk_w3x2f_kernel(LKArgs a)
@@ -59,10 +63,30 @@ __global__ __launch_bounds__(64, 2) void lk_w3x2f_kernel(LKArgs a)
                         double &w2b) __attribute__((always_inline)) {
         const float yf = (float)yw;
         const float hxA = (float)uuA / 2, hyA = (float)vvA / 2, hxB = (float)uuB / 2, hyB = (float)vvB / 2;
+#if LK_W3F_UNCOND
+        // both images of a column gathered together, unconditionally (lk_device.h remap_bilinear_x2: bit-identical): two memory
+        // round trips per marched row instead of four
+#if LK_W3F_UNCOND == 2
+        {   // all eight gathers of the row in flight at once
+            const RemapTaps t1a = remap_taps(ip, H, W, xfa + hxA, yf + hyA), t2a = remap_taps(ip, H, W, xfa - hxA, yf - hyA);
+            const RemapTaps t1b = remap_taps(ip, H, W, xfb + hxB, yf + hyB), t2b = remap_taps(ip, H, W, xfb - hxB, yf - hyB);
+            const lk_d2u g0 = *reinterpret_cast<const lk_d2u *>(I1 + t1a.off), g1 = *reinterpret_cast<const lk_d2u *>(I1 + t1a.off + ip);
+            const lk_d2u g2 = *reinterpret_cast<const lk_d2u *>(I2 + t2a.off), g3 = *reinterpret_cast<const lk_d2u *>(I2 + t2a.off + ip);
+            const lk_d2u g4 = *reinterpret_cast<const lk_d2u *>(I1 + t1b.off), g5 = *reinterpret_cast<const lk_d2u *>(I1 + t1b.off + ip);
+            const lk_d2u g6 = *reinterpret_cast<const lk_d2u *>(I2 + t2b.off), g7 = *reinterpret_cast<const lk_d2u *>(I2 + t2b.off + ip);
+            w1a = remap_blend(t1a, g0, g1, H, W); w2a = remap_blend(t2a, g2, g3, H, W);
+            w1b = remap_blend(t1b, g4, g5, H, W); w2b = remap_blend(t2b, g6, g7, H, W);
+        }
+#else
+        remap_bilinear_x2(I1, I2, ip, H, W, xfa + hxA, yf + hyA, xfa - hxA, yf - hyA, w1a, w2a);
+        remap_bilinear_x2(I1, I2, ip, H, W, xfb + hxB, yf + hyB, xfb - hxB, yf - hyB, w1b, w2b);
+#endif
+#else
         w1a = remap_bilinear(I1, ip, H, W, xfa + hxA, yf + hyA);
         w2a = remap_bilinear(I2, ip, H, W, xfa - hxA, yf - hyA);
         w1b = remap_bilinear(I1, ip, H, W, xfb + hxB, yf + hyB);
         w2b = remap_bilinear(I2, ip, H, W, xfb - hxB, yf - hyB);
+#endif
     };
     // cv::pyrUp at an arbitrary row (prologue only): vertical combination of three freshly fetched coarse rows
     auto up_at = [&](int yw, double &uuA, double &vvA, double &uuB, double &vvB) __attribute__((always_inline)) {
