@@ -26,6 +26,7 @@
 #include "lk_batch.h"
 #include "lk_w3x2.h"
 #include "lk_w3x2f.h"
+#include "lk_w3x1f.h"
 
 #define LKFLOW_VERSION_STR "lkflow-mi355x 0.3 (gfx950)"
 
@@ -557,10 +558,15 @@ bool fused_w3_applies(const lkflow_ctx *ctx, int win, int W, int H)
     static const bool off = knob("LKFLOW_NO_W3_FUSED", 0) || knob("LKFLOW_NO_W3X2", 0);
     return !off && ctx->impl == 0 && win == 3 && W >= 2 && !(W & 1) && !(H & 1);
 }
+#ifndef LKFLOW_W3_ONE_COLUMN
+#define LKFLOW_W3_ONE_COLUMN 1                      /* fused 3 x 3: one column per lane with the gathers one row ahead (lk_w3x1f.h) instead of two columns */
+#endif
 int launch_w3x2f(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
 {
-    const int bpc = blocks_per_cu(ctx, lk::lk_w3x2f_kernel, 64);
-    const int gx = (a.W + lk::W3X2_XO - 1) / lk::W3X2_XO;
+    static const int one_col = knob("LKFLOW_W3_ONE_COLUMN", LKFLOW_W3_ONE_COLUMN);   // A/B
+    const int xo = one_col ? lk::W3X1_XO : lk::W3X2_XO;
+    const int bpc = one_col ? blocks_per_cu(ctx, lk::lk_w3x1f_kernel, 64) : blocks_per_cu(ctx, lk::lk_w3x2f_kernel, 64);
+    const int gx = (a.W + xo - 1) / xo;
     int th = ctx->tile_rows > 0 ? ctx->tile_rows : pick_tile_rows(a.H, 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
     if (th > a.H) th = a.H;
     {
@@ -570,7 +576,8 @@ int launch_w3x2f(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
         if (th > cap) th = (int)cap;
     }
     a.th = th;
-    hipLaunchKernelGGL(lk::lk_w3x2f_kernel, dim3(gx, (a.H + th - 1) / th, pairs), dim3(64), 0, s, a);
+    if (one_col) hipLaunchKernelGGL(lk::lk_w3x1f_kernel, dim3(gx, (a.H + th - 1) / th, pairs), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(lk::lk_w3x2f_kernel, dim3(gx, (a.H + th - 1) / th, pairs), dim3(64), 0, s, a);
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }
@@ -717,7 +724,8 @@ int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok,
     const char *up = has_up ? "true" : "false";
     static const bool no_fused = knob("LKFLOW_NO_W3_FUSED", 0) || knob("LKFLOW_NO_W3X2", 0);
     static const bool no_x2 = knob("LKFLOW_NO_W3X2", 0) != 0, no_w3 = knob("LKFLOW_NO_W3_DPP", 0) != 0;
-    if (win == 3 && has_up && fused_ok && !no_fused && cols >= 2 && !(cols & 1) && !(rows & 1)) snprintf(buf, n, "lk::lk_w3x2f_kernel");
+    if (win == 3 && has_up && fused_ok && !no_fused && cols >= 2 && !(cols & 1) && !(rows & 1))
+        snprintf(buf, n, knob("LKFLOW_W3_ONE_COLUMN", LKFLOW_W3_ONE_COLUMN) ? "lk::lk_w3x1f_kernel" : "lk::lk_w3x2f_kernel");
     else if (win == 3 && !no_x2 && cols >= 2 && !(cols & 1)) snprintf(buf, n, "lk::lk_w3x2_kernel<%s>", up);
     else if (win == 3 && !no_w3) snprintf(buf, n, "lk::lk_march3_kernel<3, 64, %s>", up);
     else if (split_applies(win, cols, rows)) snprintf(buf, n, "lk::lk_split_kernel<%d, 2, %s, false>", win, up);   // (..., true> with LKFLOW_OPT_FUSE_WARP)
