@@ -64,45 +64,52 @@ def lk0_bytes_per_pair(cols, rows, levels, fused=False):
 
 
 def csrc_digest():
-    """sha256 over the kernel sources (optical-flow_amd/csrc/*, include/lkflow.h), names and contents, sorted: the code a
-    PMC pass or a kernel trace was measured on.  tools/pmc_summary.py stamps it into profiles/pmc_traffic.json."""
-    import hashlib
-    h = hashlib.sha256()
-    files = sorted(os.path.join(ROOT, "optical-flow_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "optical-flow_amd", "csrc")))
-    files.append(os.path.join(ROOT, "include", "lkflow.h"))
-    for f in files:
-        h.update(os.path.basename(f).encode() + b"\0")
-        with open(f, "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    """Digest of the kernel sources in the tree (__graft_entry__.csrc_digest)."""
+    import __graft_entry__
+    return __graft_entry__.csrc_digest()
 
 
-def _profile_record():
+def loaded_lib_digest():
+    """Digest of the sources the LOADED liblkflow.so was built from (the tail of lkflow_version()), or None for an A/B
+    library (LKFLOW_LIB) or one built without the stamp: committed profile numbers are attached only to the code they
+    were measured on."""
+    if os.environ.get("LKFLOW_LIB"):
+        return None
+    import lkflow_amd
+    v = lkflow_amd.lib().lkflow_version().decode()
+    return v.rsplit("src:", 1)[1] if "src:" in v else None
+
+
+def _profile_record(workload):
+    """The committed rocprofv3 record of one workload ("colsxrowsxpairs"): profiles/pmc_traffic.json holds one object per
+    workload under "workloads" (written by tools/pmc_summary.py), each stamped with the digest of the kernel sources it was
+    measured on.  {} unless that digest is the tree's AND the loaded library's."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh)
+            top = json.load(fh)
     except (OSError, ValueError):
         return {}
+    d = top.get("workloads", {}).get(workload, {})
+    sha = d.get("_csrc_sha")
+    if not sha or sha != csrc_digest() or sha != loaded_lib_digest():
+        return {}
+    return d
 
 
 def measured_traffic(kernel_name, cols, rows, pairs):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/pmc_traffic.json,
     written by tools/prof_pmc.sh for THIS workload and THIS code: the file carries the digest of the kernel sources it was
     measured on), or None -- a stale file after a kernel change must not be reported as a measurement."""
-    d = _profile_record()
-    if d.get("_workload") != f"{cols}x{rows}x{pairs}" or d.get("_csrc_sha") != csrc_digest():
-        return None
+    d = _profile_record(f"{cols}x{rows}x{pairs}")
     v = d.get(kernel_name)
-    return int(v["hbm_read_bytes"] + v["hbm_write_bytes"]) if isinstance(v, dict) else None
+    return int(v["hbm_read_bytes"] + v["hbm_write_bytes"]) if isinstance(v, dict) and "hbm_read_bytes" in v else None
 
 
 def rocprof_avg_launch_ms(kernel_name, cols, rows, pairs):
     """Mean duration of the dominant kernel's level-0 dispatches in the committed rocprofv3 --kernel-trace of the same
     command (stamped into profiles/pmc_traffic.json by tools/prof_round.sh), or None if the code has changed since."""
-    d = _profile_record()
-    if d.get("_workload") != f"{cols}x{rows}x{pairs}" or d.get("_csrc_sha") != csrc_digest():
-        return None
+    d = _profile_record(f"{cols}x{rows}x{pairs}")
     v = d.get(kernel_name)
     return v.get("rocprof_avg_launch_ms") if isinstance(v, dict) else None
 

@@ -93,7 +93,8 @@ int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int 
                                   8-wave workgroups, 8 rows per barrier pair, 5 window-sum waves next to 3 producer waves)
                                   instead of the wave-specialised one.  Same expressions; the vertical window sums are
                                   associated in chunks of win + 1 instead of win rows (agreement ~1e-15 relative).  Experimental:
-                                  measured slower (round-3 record in DESIGN.md). */
+                                  measured slower (round-3 record in DESIGN.md).  Only in a -DLKFLOW_EXPERIMENTAL build of the
+                                  library (tools/build_variant.sh); the shipped one answers LKFLOW_E_ARG to value 1. */
 int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value);
 
 /* Stage ids of the kernels the pyramid driver launches (level = pyramid level the launch works at;
@@ -272,6 +273,41 @@ int lkflow_diff_edge_map_u8_dev(lkflow_ctx *ctx, const unsigned char *cur, const
 int lkflow_flow_centroid_f64_dev(lkflow_ctx *ctx, const double *U, const double *V,
                                  size_t uv_pair_stride_bytes, int n_pairs, int rows, int cols,
                                  size_t uv_step_bytes, double thresh, double *out, void *stream);
+
+/* ---- frame-queue engine over a device list (SURVEY.md 8(b) "lkflow_ctx_create(devices...), lkflow_enqueue_pair,
+ * lkflow_wait"; 8(e)) -------------------------------------------------------------------------------------------------
+ * The reference's video loop (ParallelVideoPyr.cpp:769-873) for a caller that holds a whole stream of 8-bit frames in ONE
+ * process: F frames = F - 1 consecutive frame pairs, partitioned over the listed devices in contiguous blocks with a
+ * one-frame overlap (device k of n gets frames [first_k, first_k + n_k): lkflow_stream_block, the rule of SURVEY.md 8(e));
+ * one worker thread + context + HIP stream per list entry (a device may be listed more than once).  Per block: uint8
+ * frames host -> device, convertTo(CV_64FC1, 1/255) on the device (SerialPyr.cpp:237), coarseToFineEstimation on the
+ * block's pairs (inputs not mutated: pairs are independent), the consumer's |flow| >= thresh centroid sums
+ * (ParallelVideoPyr.cpp:845-873); 3 doubles per pair come back.  Every pair's result is bit-identical to the pair computed
+ * alone on any device, so the output does not depend on the device list.  No collective is involved (one process; the
+ * multi-process form over RCCL is optical-flow_amd/sharding.py + bench.py --gpus N). */
+typedef struct lkflow_stream lkflow_stream;
+#define LKFLOW_STREAM_KEEP_FLOW 1u /* keep every pair's U, V on its device for lkflow_stream_flow (2 planes per pair) */
+int lkflow_stream_create(lkflow_stream **out, const int *devices, int n_devices, int rows, int cols, int pyr_levels,
+                         int win, unsigned flags);
+void lkflow_stream_destroy(lkflow_stream *s);
+/* Device memory one worker may use per lkflow_compute_batch_f64_dev call (default 16 GiB): a block is processed in chunks
+ * of pairs that fit it.  Results do not depend on it. */
+int lkflow_stream_set_budget(lkflow_stream *s, size_t bytes_per_device);
+/* Start the flow of a stream: n_frames >= 2 frames of rows x cols bytes in HOST memory, frame f at frames + f *
+ * frame_stride_bytes, row step step_bytes.  Returns at once; the frames must stay valid and unchanged until
+ * lkflow_stream_centroids / _flow / _destroy has returned.  One push may be in flight: another first completes it. */
+int lkflow_stream_push_u8(lkflow_stream *s, const unsigned char *frames, int n_frames, size_t frame_stride_bytes,
+                          size_t step_bytes, double thresh);
+/* Wait for the push; out[3*p + {0,1,2}] = count, sum of column indices, sum of row indices of pair p's pixels with
+ * sqrt(u*u + v*v) >= thresh (lkflow_flow_centroid_f64_dev's numbers).  n_pairs must be n_frames - 1.  A worker's failure
+ * is reported here (lkflow_stream_last_error names the device). */
+int lkflow_stream_centroids(lkflow_stream *s, double *out, int n_pairs);
+/* U, V of one pair of the last push into host buffers (only with LKFLOW_STREAM_KEEP_FLOW). */
+int lkflow_stream_flow(lkflow_stream *s, int pair, double *U, double *V, size_t uv_step_bytes);
+/* The partition rule: frames [*first_frame, *first_frame + *n_frames_local) for list entry k of n_devices
+ * (*n_frames_local == 0: more devices than pairs, the entry idles). */
+int lkflow_stream_block(int n_frames, int n_devices, int k, int *first_frame, int *n_frames_local);
+const char *lkflow_stream_last_error(const lkflow_stream *s);
 
 #ifdef __cplusplus
 }

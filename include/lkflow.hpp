@@ -112,7 +112,10 @@ public:
     void enqueue(const Mat &prev, const Mat &next, Mat &U, Mat &V, int pyr_levels, int win = 3, unsigned flags = 0)
     {
         check_pair(prev, next);
-        finish_staged();
+        // A pair still in flight may be copying from / into the engine-owned staging buffer (unequal steps): complete it
+        // BEFORE that buffer is read back, rewritten or re-allocated (the C ABI's own "second enqueue waits for the first"
+        // happens inside lkflow_enqueue_pair_f64, i.e. too late for staged_).
+        drain();
         seat_outputs(U, V, prev.rows, prev.cols);
         double *nx = mat_data(next);
         if (mat_step(next) != mat_step(prev)) {
@@ -120,39 +123,37 @@ public:
             // the pair with ONE row step: `next` goes through an engine-owned buffer with prev's step (and comes back from
             // it after the call when the level-0 warp overwrites the inputs, ParallelVideoPyr.cpp:696,701).
             const size_t st = mat_step(prev), row = (size_t)prev.cols * sizeof(double);
-            staged_.assign((size_t)prev.rows * st / sizeof(double) + 1, 0.0);
-            for (int y = 0; y < prev.rows; ++y)
-                std::memcpy(reinterpret_cast<unsigned char *>(staged_.data()) + (size_t)y * st,
-                            reinterpret_cast<const unsigned char *>(mat_data(next)) + (size_t)y * mat_step(next), row);
+            stage_rows(reinterpret_cast<const unsigned char *>(mat_data(next)), mat_step(next), prev.rows, st, row);
             nx = staged_.data();
             if (flags & LKFLOW_MUTATE_INPUTS) {
                 back_dst_ = reinterpret_cast<unsigned char *>(mat_data(next)); back_step_ = mat_step(next);
                 back_rows_ = prev.rows; back_row_bytes_ = row; back_src_step_ = st;
             }
         }
-        check(lkflow_enqueue_pair_f64(ctx_, mat_data(prev), nx, prev.rows, prev.cols, mat_step(prev),
-                                      mat_data(U), mat_data(V), mat_step(U), pyr_levels, win, flags));
+        const int rc = lkflow_enqueue_pair_f64(ctx_, mat_data(prev), nx, prev.rows, prev.cols, mat_step(prev),
+                                               mat_data(U), mat_data(V), mat_step(U), pyr_levels, win, flags);
+        if (rc != LKFLOW_OK) back_dst_ = nullptr;             // (a failed enqueue has drained its stream and written nothing back)
+        else inflight_ = true;
+        check(rc);
     }
-    void wait()
-    {
-        check(lkflow_wait(ctx_));
-        finish_staged();
-    }
+    void wait() { drain(); }
     // Page-lock the (re-used) Mats of a video loop in place: see LKFLOW_OPT_PIN_HOST in lkflow.h.
-    void pinHostBuffers(bool on) { check(lkflow_ctx_set_option(ctx_, LKFLOW_OPT_PIN_HOST, on ? 1 : 0)); }
+    void pinHostBuffers(bool on)
+    {
+        drain();
+        check(lkflow_ctx_set_option(ctx_, LKFLOW_OPT_PIN_HOST, on ? 1 : 0));
+        pinned_ = on;
+    }
 
     void getLucasKanadeOpticalFlow(const Mat &img1, const Mat &img2, Mat &u, Mat &v, int win = 3)
     {
         check_pair(img1, img2);
-        finish_staged();
+        drain();                                             // (as in enqueue(): before staged_ is touched)
         seat_outputs(u, v, img1.rows, img1.cols);
         const double *p2 = mat_data(img2);
         if (mat_step(img2) != mat_step(img1)) {              // (as in enqueue(): one row step per pair in the C ABI)
-            const size_t st = mat_step(img1), row = (size_t)img1.cols * sizeof(double);
-            staged_.assign((size_t)img1.rows * st / sizeof(double) + 1, 0.0);
-            for (int y = 0; y < img1.rows; ++y)
-                std::memcpy(reinterpret_cast<unsigned char *>(staged_.data()) + (size_t)y * st,
-                            reinterpret_cast<const unsigned char *>(mat_data(img2)) + (size_t)y * mat_step(img2), row);
+            stage_rows(reinterpret_cast<const unsigned char *>(mat_data(img2)), mat_step(img2), img1.rows, mat_step(img1),
+                       (size_t)img1.cols * sizeof(double));
             p2 = staged_.data();
         }
         check(lkflow_lk_f64(ctx_, mat_data(img1), p2, img1.rows, img1.cols, mat_step(img1),
@@ -188,6 +189,33 @@ private:
             throw std::runtime_error(msg + " [" + lkflow_last_error(ctx_) + "]");
         throw std::invalid_argument(msg);
     }
+    // Complete the pair in flight (if any), then hand a staged, overwritten `next` back.  Every path that reads, rewrites
+    // or re-allocates staged_ goes through here first.
+    void drain()
+    {
+        if (inflight_) {
+            inflight_ = false;
+            const int rc = lkflow_wait(ctx_);
+            if (rc != LKFLOW_OK) back_dst_ = nullptr;
+            check(rc);
+        }
+        finish_staged();
+    }
+    // Copy `rows` rows of `row` bytes (source step sstep) into the staging buffer with step st.  The buffer only ever GROWS,
+    // and only here, i.e. after drain(): nothing is in flight on it.  With pinHostBuffers(true) the library has page-locked
+    // the old allocation in place (LKFLOW_OPT_PIN_HOST registers the ranges it is handed): those registrations are dropped
+    // BEFORE the vector frees it, and the option is switched back on for the new one.
+    void stage_rows(const unsigned char *src, size_t sstep, int rows, size_t st, size_t row)
+    {
+        const size_t need = (size_t)rows * st / sizeof(double) + 1;
+        if (need > staged_.size()) {
+            if (pinned_) check(lkflow_ctx_set_option(ctx_, LKFLOW_OPT_PIN_HOST, 0));
+            staged_.assign(need, 0.0);
+            if (pinned_) check(lkflow_ctx_set_option(ctx_, LKFLOW_OPT_PIN_HOST, 1));
+        }
+        for (int y = 0; y < rows; ++y)
+            std::memcpy(reinterpret_cast<unsigned char *>(staged_.data()) + (size_t)y * st, src + (size_t)y * sstep, row);
+    }
     // copy a staged, overwritten `next` back into the caller's matrix (LKFLOW_MUTATE_INPUTS with unequal steps)
     void finish_staged()
     {
@@ -203,6 +231,60 @@ private:
     unsigned char *back_dst_ = nullptr;
     size_t back_step_ = 0, back_src_step_ = 0, back_row_bytes_ = 0;
     int back_rows_ = 0;
+    bool inflight_ = false, pinned_ = false;
+};
+
+// The frame-queue engine over a device list (lkflow_stream_* in lkflow.h): the reference's video loop
+// (ParallelVideoPyr.cpp:769-873) for a whole stream of 8-bit frames, frame pairs partitioned over the GPUs of one node inside
+// ONE process.  push() returns at once; centroids() waits and returns {count, sum x, sum y} per pair (the consumer's sums,
+// :845-873; gestureCentroid() below turns a row into the circle the reference draws).
+class StreamEngine {
+public:
+    StreamEngine(const std::vector<int> &devices, int rows, int cols, int pyr_levels, int win = 3, bool keep_flow = false)
+        : rows_(rows), cols_(cols)
+    {
+        const int rc = lkflow_stream_create(&s_, devices.data(), (int)devices.size(), rows, cols, pyr_levels, win,
+                                            keep_flow ? LKFLOW_STREAM_KEEP_FLOW : 0u);
+        if (rc == LKFLOW_E_HIP || rc == LKFLOW_E_NOMEM || rc == LKFLOW_E_NODEVICE)
+            throw std::runtime_error(std::string("lkflow_stream_create: ") + lkflow_strerror(rc));
+        if (rc != LKFLOW_OK) throw std::invalid_argument(std::string("lkflow_stream_create: ") + lkflow_strerror(rc));
+    }
+    ~StreamEngine() { lkflow_stream_destroy(s_); }
+    StreamEngine(const StreamEngine &) = delete;
+    StreamEngine &operator=(const StreamEngine &) = delete;
+    lkflow_stream *handle() const { return s_; }
+
+    // n_frames contiguous 8-bit frames (rows x cols each, row step = cols unless given); they must outlive the push
+    void push(const unsigned char *frames, int n_frames, double thresh = 20.0, size_t frame_stride_bytes = 0, size_t step_bytes = 0)
+    {
+        const size_t st = step_bytes ? step_bytes : (size_t)cols_, fs = frame_stride_bytes ? frame_stride_bytes : st * (size_t)rows_;
+        check(lkflow_stream_push_u8(s_, frames, n_frames, fs, st, thresh));
+        n_pairs_ = n_frames - 1;
+    }
+    std::vector<double> centroids()                          // [n_pairs][3], row-major
+    {
+        std::vector<double> out((size_t)n_pairs_ * 3);
+        check(lkflow_stream_centroids(s_, out.data(), n_pairs_));
+        return out;
+    }
+    void flow(int pair, Mat &U, Mat &V)                      // needs keep_flow
+    {
+        mat_create(U, rows_, cols_); mat_create(V, rows_, cols_);
+        if (mat_step(U) != mat_step(V)) { U = Mat(); V = Mat(); mat_create(U, rows_, cols_); mat_create(V, rows_, cols_); }
+        check(lkflow_stream_flow(s_, pair, mat_data(U), mat_data(V), mat_step(U)));
+    }
+    int pairs() const { return n_pairs_; }
+
+private:
+    void check(int rc) const
+    {
+        if (rc == LKFLOW_OK) return;
+        const std::string msg = std::string("lkflow stream: ") + lkflow_strerror(rc) + " [" + lkflow_stream_last_error(s_) + "]";
+        if (rc == LKFLOW_E_HIP || rc == LKFLOW_E_NOMEM || rc == LKFLOW_E_NODEVICE) throw std::runtime_error(msg);
+        throw std::invalid_argument(msg);
+    }
+    lkflow_stream *s_ = nullptr;
+    int rows_, cols_, n_pairs_ = 0;
 };
 
 inline Engine &default_engine()

@@ -89,6 +89,23 @@ __device__ __forceinline__ void lk_solve(const double s[5], double &u, double &v
     v = det != 0.0 ? vn / det : 0.0;
 }
 
+// The reference's 3 x 3 window sum, get_Sum9 (ParallelVideoPyr.cpp:114-160, loop form SerialPyr.cpp:80-96): val = 0, then
+// nine sequential additions in row-major order, ((((((((t0 + t1) + t2) + m0) + m1) + m2) + b0) + b1) + b2).  A row-marching
+// kernel meets the rows of a window one at a time, so per field and column it carries the partial of the window whose TOP
+// row was the previous marched row (a) and of the window whose top and middle rows were the two previous rows (b); the
+// marched row (l, c, r) completes the second, extends the first and opens a new one: 8 additions per field against 4 for
+// the separable order of rounds 1-3, and in return the 3 x 3 path has the reference's bits wherever a window holds nothing
+// but rounding residue (straight edges, singular structure tensors -- the reference's own edge-map inputs).  The result
+// does not depend on where a strip starts.  (0.0 + t0 is t0 up to the sign of a zero.)
+struct Sum9 { double a, b; };
+__device__ __forceinline__ double sum9_step(Sum9 &s, double l, double c, double r)
+{
+    const double S = ((s.b + l) + c) + r;
+    s.b = ((s.a + l) + c) + r;
+    s.a = (l + c) + r;
+    return S;
+}
+
 // Horizontal pass of cv::pyrUp at fine column x for one coarse row c[0..Wc) (OpenCV 2.4
 // pyramids.cpp pyrUp_; asymmetric borders exactly as the template writes them).
 __device__ __forceinline__ double pyrup_h(const double *c, int Wc, int x)

@@ -120,6 +120,9 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
 #pragma unroll
         for (int f = 0; f < 5; ++f) ring[q][f] = 0.0;
     double pre[5] = {0, 0, 0, 0, 0};
+    [[maybe_unused]] Sum9 win9[5];                             // WIN == 3: partial window sums in the reference's order (lk_device.h)
+#pragma unroll
+    for (int f = 0; f < 5; ++f) win9[f].a = win9[f].b = 0.0;
 
     // byte offset of image row yy (reflected into the image; apron rows carry the reflect-101 row, so that at
     // yy = 0 the "previous" row is row 1 = r101(-1); one reflection suffices unless the image is shorter than
@@ -253,19 +256,20 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
         double S[5];
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
-            double h;
+            double h = 0.0;
             if constexpr (DPP_ONLY) {
-                // 3-tap window inside one wave: both neighbours by DPP wave shifts, no LDS, no barrier
-                h = (dpp_wave_shr1(p[f]) + p[f]) + dpp_wave_shl1(p[f]);
+                // 3-tap window inside one wave: both neighbours by DPP wave shifts, no LDS, no barrier; the nine terms in
+                // get_Sum9's own order
+                S[f] = sum9_step(win9[f], dpp_wave_shr1(p[f]), p[f], dpp_wave_shl1(p[f]));
             } else {
                 const double *q = &s_q[bsel][f][PQ + jb];
                 h = s_p[bsel][f][PP + sidx];
 #pragma unroll
                 for (int j = 0; j < R; ++j) h += q[j];
             }
-            if constexpr (WIN == 3) {
-                // three rows: summed directly, (row i-2 + row i-1) + row i -- one fixed order for every row, so the
-                // result does not depend on where a strip starts (see the chunk anchoring below)
+            if constexpr (DPP_ONLY) {
+            } else if constexpr (WIN == 3) {
+                // (multi-wave blocks, never launched for 3 x 3) three rows summed directly, (row i-2 + row i-1) + row i
                 S[f] = (ring[(K + 1) % 3][f] + ring[(K + 2) % 3][f]) + h;
                 ring[K][f] = h;
             } else {

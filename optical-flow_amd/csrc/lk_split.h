@@ -70,6 +70,9 @@
 #ifndef LK_SPLIT_QSUM_ABOVE
 #define LK_SPLIT_QSUM_ABOVE 21   /* windows above this: F publishes the pair sums (SplitCfg::QSUM) */
 #endif
+#ifndef LK_SPLIT_FW_WPE
+#define LK_SPLIT_FW_WPE 3  /* fused warp: 12-wave workgroups, one per CU (three waves per SIMD: <= 168 VGPRs) */
+#endif
 #ifndef LK_SPLIT_TD
 #define LK_SPLIT_TD 2    /* even: row pairs of coarse taps a B lane keeps in flight (4 spills at 15x15 and is slower) */
 #endif
@@ -83,7 +86,7 @@ typedef double lk_d2 __attribute__((ext_vector_type(2)));
 template <int WIN, int K, bool FW = false>
 struct SplitCfg {
     static constexpr int R = WIN / 2;
-    static constexpr int NWW = FW ? K : 0;                    // W waves (fused warp): 64 columns each, one column per lane
+    static constexpr int NWW = FW ? 2 * K : 0;                // W waves (fused warp): 64 columns and ONE row of the step's pair each, one column per lane
     static constexpr int LAG = FW ? 2 : 0;           // pipeline steps the W role runs ahead of F
     static constexpr int PF = LK_SPLIT_PF;           // image rows in flight per F lane: a pipeline step is short, HBM latency is not
     static constexpr int NB = K;                     // B waves: 64 columns each
@@ -117,7 +120,7 @@ struct SplitCfg {
     static constexpr int PROD_D = KH * PSTR * 2;     // doubles per product plane
     static constexpr int SUMS_D = KH * SSTR * 2;     // doubles per sums plane
     // waves per SIMD to compile for (8-wave blocks: 4 -> two blocks per CU; 10-wave blocks with the W role: 5 -> two blocks)
-    static constexpr int WPE = FW ? 5 : ((K == 2 && WIN <= LK_SPLIT_TWO_WG_MAX) ? 4 : (NF == 2 ? 3 : 1));   // nine waves: three on one SIMD
+    static constexpr int WPE = FW ? LK_SPLIT_FW_WPE : ((K == 2 && WIN <= LK_SPLIT_TWO_WG_MAX) ? 4 : (NF == 2 ? 3 : 1));   // nine waves: three on one SIMD
     // F publishes the pair sums a + b (true) or S adds the raw pairs itself (false).  Up to 21 x 21 (two workgroups per CU)
     // F is the wave that paces a workgroup and S has slack: S adds (4K/L5/w21 28.4 -> 30.2 Gpx/s).  From 23 x 23 on (one
     // workgroup per CU, 16 LDS reads per row and field) the S waves' LDS reads are the longer pole: halving their bytes
@@ -187,23 +190,82 @@ __device__ __forceinline__ void lk_border_pixel(const LKArgs &a, int win, unsign
     const bool ring = !(y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2);                    // outermost ring: 0 (+ pyrUp)
     double S[5], u = 0.0, v = 0.0;
     if constexpr (FW) {
-      if (!ring) {
-        // fused warp: a.i1 / a.i2 are the UN-warped level images; the four warped taps of both images are made here
-        // (cv::pyrUp of the coarse flow at the tap, float map, remap: warp_kernel's arithmetic)
-        const double *I1 = a.i1.at(pair), *I2 = a.i2.at(pair), *cu = a.cu.at(pair), *cv = a.cv.at(pair);
-        const int ym = y - 1, xm = x - 1;
-        auto warped = [&](int yy, int xx, double &w1, double &w2) {
-            const float hx = (float)pyrup_at(cu, a.cu.pitch, H >> 1, W >> 1, yy, xx) / 2;
-            const float hy = (float)pyrup_at(cv, a.cv.pitch, H >> 1, W >> 1, yy, xx) / 2;
-            w1 = remap_bilinear(I1, (int)a.i1.pitch, H, W, (float)xx + hx, (float)yy + hy);
-            w2 = remap_bilinear(I2, (int)a.i2.pitch, H, W, (float)xx - hx, (float)yy - hy);
-        };
-        double a00, a01, a10, a11, b00, b01, b10, b11;
-        warped(ym, xm, a00, b00); warped(ym, x, a01, b01); warped(y, xm, a10, b10); warped(y, x, a11, b11);
-        lk_products(a00, a01, a10, a11, b00, b01, b10, b11, S);
+        // Fused warp: a.i1 / a.i2 are the UN-warped level images, so the four derivative taps (rows yc - 1, yc x columns
+        // xc - 1, xc, all inside the image for a pixel inside the ring; ring pixels compute a neighbour's and drop it) of
+        // both images are MADE here: cv::pyrUp of the coarse flow at the four positions from ONE 3-row x 6-tap patch per
+        // flow plane (rows s(i-1), s(i), s(i+1), i = yc >> 1, cover both rows; make_upsel1 / pyrup_h1v: the main kernel's
+        // roundings), float map, fixed-point remap with all sixteen gathers issued unconditionally and together
+        // (lk_device.h remap_taps / remap_blend: warp_kernel's bits).  Straight-line, no load under a condition.
+        const int yc = max(y, 1), xc = max(x, 1);
+        const int Hc = H >> 1, Wc = W >> 1, i = yc >> 1;
+        const UpSel1 usc[2] = {make_upsel1(xc - 1, Wc), make_upsel1(xc, Wc)};
+        const double *cu = a.cu.at(pair), *cv = a.cv.at(pair);
+        double tu[3][2][3], tv[3][2][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = i - 1 + q;
+            const int sr = k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k);
+            const char *pu = reinterpret_cast<const char *>(cu + (long long)sr * a.cu.pitch);
+            const char *pv = reinterpret_cast<const char *>(cv + (long long)sr * a.cv.pitch);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                tu[q][c][0] = *reinterpret_cast<const double *>(pu + usc[c].jm); tu[q][c][1] = *reinterpret_cast<const double *>(pu + usc[c].jc);
+                tu[q][c][2] = *reinterpret_cast<const double *>(pu + usc[c].jp);
+                tv[q][c][0] = *reinterpret_cast<const double *>(pv + usc[c].jm); tv[q][c][1] = *reinterpret_cast<const double *>(pv + usc[c].jc);
+                tv[q][c][2] = *reinterpret_cast<const double *>(pv + usc[c].jp);
+            }
+        }
+        double upu[2][2], upv[2][2];                                   // [row yc - 1, yc][column xc - 1, xc]
+        const bool yodd = (yc & 1) != 0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            double hu[3], hv[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                hu[q] = pyrup_h1v(tu[q][c][0], tu[q][c][1], tu[q][c][2], usc[c]);
+                hv[q] = pyrup_h1v(tv[q][c][0], tv[q][c][1], tv[q][c][2], usc[c]);
+            }
+            const double ue = (hu[0] + hu[1] * 6 + hu[2]) * (1.0 / 64), ve = (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);   // the even row of the two
+            // the odd row: below the even one (yc odd: rows s(i), s(i+1)) or above it (yc even: rows s(i-1), s(i))
+            const double uo = (((yodd ? hu[1] : hu[0]) + (yodd ? hu[2] : hu[1])) * 4) * (1.0 / 64);
+            const double vo = (((yodd ? hv[1] : hv[0]) + (yodd ? hv[2] : hv[1])) * 4) * (1.0 / 64);
+            upu[0][c] = yodd ? ue : uo; upu[1][c] = yodd ? uo : ue;
+            upv[0][c] = yodd ? ve : vo; upv[1][c] = yodd ? vo : ve;
+        }
+        const double *I1 = a.i1.at(pair), *I2 = a.i2.at(pair);
+        const int ip = (int)a.i1.pitch;
+        RemapTaps t1[2][2], t2[2][2];
+        lk_d2u g1[2][2][2], g2[2][2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float xf = (float)(xc - 1 + c), yf = (float)(yc - 1 + r);
+                const float hx = (float)upu[r][c] / 2, hy = (float)upv[r][c] / 2;      // map build (ParallelVideoPyr.cpp:674-678), float32
+                t1[r][c] = remap_taps(ip, H, W, xf + hx, yf + hy);
+                t2[r][c] = remap_taps(ip, H, W, xf - hx, yf - hy);
+                g1[r][c][0] = *reinterpret_cast<const lk_d2u *>(I1 + t1[r][c].off); g1[r][c][1] = *reinterpret_cast<const lk_d2u *>(I1 + t1[r][c].off + ip);
+                g2[r][c][0] = *reinterpret_cast<const lk_d2u *>(I2 + t2[r][c].off); g2[r][c][1] = *reinterpret_cast<const lk_d2u *>(I2 + t2[r][c].off + ip);
+            }
+        double wa[2][2], wb[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                wa[r][c] = remap_blend(t1[r][c], g1[r][c][0], g1[r][c][1], H, W);
+                wb[r][c] = remap_blend(t2[r][c], g2[r][c][0], g2[r][c][1], H, W);
+            }
+        lk_products(wa[0][0], wa[0][1], wa[1][0], wa[1][1], wb[0][0], wb[0][1], wb[1][0], wb[1][1], S);
         for (int f = 0; f < 5; ++f) S[f] = S[f] * (double)(win * win);
-        lk_solve(S, u, v);
-      }
+        double us_, vs_;
+        lk_solve(S, us_, vs_);
+        // "+= pyrUp" at (y, x) itself: one of the four positions (a ring pixel sits on row yc - 1 and / or column xc - 1)
+        const int rr = y == yc ? 1 : 0, cc = x == xc ? 1 : 0;
+        u = (ring ? 0.0 : us_) + (rr ? (cc ? upu[1][1] : upu[1][0]) : (cc ? upu[0][1] : upu[0][0]));
+        v = (ring ? 0.0 : vs_) + (rr ? (cc ? upv[1][1] : upv[1][0]) : (cc ? upv[0][1] : upv[0][0]));
+        a.u.at(pair)[(long long)y * a.u.pitch + x] = u;
+        a.v.at(pair)[(long long)y * a.v.pitch + x] = v;
+        return;
     } else {
         // Straight-line: every load is issued up front from an address that is valid for ring pixels too (their products
         // are computed and dropped), so that the image taps and the coarse-flow taps are in flight together.  A pixel
@@ -340,18 +402,25 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     if (FW && wv > C::NB + 5) {
       if constexpr (FW) {                            // (not even compiled for the unfused kernel)
         // =========================================================================================
-        // W waves (fused warp, a9-a12): one column per lane -> the warped rows of both images, through LDS to F
+        // W waves (fused warp, a9-a12): one column per lane, ONE row of the step's pair per wave -> the warped rows of both
+        // images, through LDS to F
         // =========================================================================================
         // cv::pyrUp of the coarse flow (incremental: the three horizontally filtered coarse rows of the current row
         // pair are carried in registers; the new row of a step comes from F's coarse-row service through LDS), float
         // map, 1/32-pixel fixed-point bilinear remap with fp64 blend: warp_kernel's arithmetic bit for bit (lk_kernels.h,
         // lk_device.h remap_bilinear).  W-step t produces the marched rows yy0 - 2 + 2t and yy0 - 1 + 2t into plane
-        // t & 1; F reads them in step t + 1 (so F-step s runs in pipeline step s + 2).  Software pipeline: step t blends
-        // the taps gathered for step t, issues the gathers of step t + 1 (addresses ready since step t - 1) and then
-        // computes the addresses of step t + 2 while they fly.  Gathers are unconditional, from clamped addresses: taps
-        // that fall outside the image are zeroed afterwards (BORDER_CONSTANT 0) in a wave-uniform branch that holds no
+        // t & 1; F reads them in step t + 1 (so F-step s runs in pipeline step s + 2).  Four W waves: wave (half, e) makes
+        // row e of the pair for 64 of the 128 columns (round 4; round 2 ran two waves with both rows each, whose
+        // instruction stream was twice as long as any other role's and paced the workgroup).  Software pipeline: step t
+        // blends the taps gathered for step t, issues the gathers of step t + 1 (addresses ready since step t - 1) and
+        // then computes the addresses of step t + 2 while they fly.  Gathers are unconditional, from clamped addresses:
+        // taps that fall outside the image are zeroed afterwards (BORDER_CONSTANT 0) in a wave-uniform branch that holds no
         // memory instruction.
-        const int g = ltid - 64 * (C::NB + 6);       // block column g - 2: the two columns of F lane g >> 1
+        const int widx = wv - (C::NB + 6);           // 0 .. NWW-1
+#ifdef LK_SPLIT_PRIO_W
+        __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_W);
+#endif
+        const int g = (widx & 1) * 64 + ((int)threadIdx.x & 63);   // block column g - 2: the two columns of F lane g >> 1
         const int Hc = H >> 1, Wc = W >> 1;
         const int xcol = min(max(x0 + 2 * ((g >> 1) - 1), 0), W - 2) + (g & 1);   // F's clamped column pair
         const float xf = (float)xcol;
@@ -359,79 +428,74 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         const long long img_bytes = ((long long)(H - 1) * a.i1.pitch + W) * 8;
         const __amdgpu_buffer_rsrc_t rI1 = buf_rsrc(a.i1.at(pair), img_bytes);
         const __amdgpu_buffer_rsrc_t rI2 = buf_rsrc(a.i2.at(pair), img_bytes);
+        auto wrole = [&](auto ec) __attribute__((always_inline)) {
+        constexpr int E = decltype(ec)::value;       // this wave's row of every step's pair
         double hu[3], hv[3];
-        struct WAddr { int vo[2][2], sx[2][2], sy[2][2]; };
-        // rotation of W-step t with the new coarse row (nu, nv), up-sampled flow of its two rows, map, fixed-point coordinates
+        struct WAddr { int vo[2], sx[2], sy[2]; };   // per image
+        // rotation of W-step t with the new coarse row (nu, nv), up-sampled flow of this wave's row, map, fixed-point coordinates
         auto waddr = [&](int t, double nu, double nv, WAddr &A) __attribute__((always_inline)) {
             const int ye = ye0 + 2 * t;
             const bool rot = ye >= 2 && ye <= H - 1;
-            double uu[2], vv[2];
-            auto odd_up = [&](int e) __attribute__((always_inline)) {
-                uu[e] = ((hu[1] + hu[2]) * 4) * (1.0 / 64); vv[e] = ((hv[1] + hv[2]) * 4) * (1.0 / 64);
-            };
-            auto even_up = [&](int e) __attribute__((always_inline)) {
-                uu[e] = (hu[0] + hu[1] * 6 + hu[2]) * (1.0 / 64); vv[e] = (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);
-            };
-            if constexpr (EV == 1) odd_up(0);                           // the odd row above the even one: before the rotation
+            double uu = 0.0, vv = 0.0;
+            if constexpr (EV == 1 && E == 0) {                          // the odd row above the even one: before the rotation
+                uu = ((hu[1] + hu[2]) * 4) * (1.0 / 64); vv = ((hv[1] + hv[2]) * 4) * (1.0 / 64);
+            }
             if (rot) {
                 hu[0] = hu[1]; hu[1] = hu[2]; hu[2] = nu;
                 hv[0] = hv[1]; hv[1] = hv[2]; hv[2] = nv;
             }
-            even_up(EV);
-            if constexpr (EV == 0) odd_up(1);
+            if constexpr (E == EV) {
+                uu = (hu[0] + hu[1] * 6 + hu[2]) * (1.0 / 64); vv = (hv[0] + hv[1] * 6 + hv[2]) * (1.0 / 64);
+            }
+            if constexpr (EV == 0 && E == 1) {
+                uu = ((hu[1] + hu[2]) * 4) * (1.0 / 64); vv = ((hv[1] + hv[2]) * 4) * (1.0 / 64);
+            }
+            const int yy = yy0 - 2 + 2 * t + E;
+            // rows outside the image: only row -1 is ever used (filter2D's reflect-101 tap of row 0) = row 1; the
+            // others feed products that F zeroes, any in-image row will do
+            const float yf = (float)min(yy < 0 ? -yy : yy, H - 1);
+            const float hx = (float)uu / 2, hy = (float)vv / 2;   // map build (ParallelVideoPyr.cpp:674-678), float32
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int yy = yy0 - 2 + 2 * t + e;
-                // rows outside the image: only row -1 is ever used (filter2D's reflect-101 tap of row 0) = row 1; the
-                // others feed products that F zeroes, any in-image row will do
-                const float yf = (float)min(yy < 0 ? -yy : yy, H - 1);
-                const float hx = (float)uu[e] / 2, hy = (float)vv[e] / 2;   // map build (ParallelVideoPyr.cpp:674-678), float32
-#pragma unroll
-                for (int im = 0; im < 2; ++im) {
-                    const float mx = im ? xf - hx : xf + hx, my = im ? yf - hy : yf + hy;
-                    const int sx = cv_round_f(mx * 32.0f), sy = cv_round_f(my * 32.0f);
-                    const int ixc = min(max(sat_short(sx >> 5), 0), W - 2), iyc = min(max(sat_short(sy >> 5), 0), H - 2);
-                    A.vo[e][im] = iyc * ipb + ixc * 8;
-                    A.sx[e][im] = sx; A.sy[e][im] = sy;
-                }
+            for (int im = 0; im < 2; ++im) {
+                const float mx = im ? xf - hx : xf + hx, my = im ? yf - hy : yf + hy;
+                const int sx = cv_round_f(mx * 32.0f), sy = cv_round_f(my * 32.0f);
+                const int ixc = min(max(sat_short(sx >> 5), 0), W - 2), iyc = min(max(sat_short(sy >> 5), 0), H - 2);
+                A.vo[im] = iyc * ipb + ixc * 8;
+                A.sx[im] = sx; A.sy[im] = sy;
             }
         };
-        lk_d2 G[2][2][2];                            // gathers in flight: [row of the step][image][tap row] = columns (ixc, ixc + 1)
+        lk_d2 G[2][2];                               // gathers in flight: [image][tap row] = columns (ixc, ixc + 1)
         auto wissue = [&](const WAddr &A) __attribute__((always_inline)) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int im = 0; im < 2; ++im) {
-                    const __amdgpu_buffer_rsrc_t rI = im ? rI2 : rI1;
-                    double g0x, g0y, g1x, g1y;
-                    buf_ld2(rI, A.vo[e][im], 0, g0x, g0y);
-                    buf_ld2(rI, A.vo[e][im], ipb, g1x, g1y);
-                    G[e][im][0].x = g0x; G[e][im][0].y = g0y; G[e][im][1].x = g1x; G[e][im][1].y = g1y;
-                }
+            for (int im = 0; im < 2; ++im) {
+                const __amdgpu_buffer_rsrc_t rI = im ? rI2 : rI1;
+                double g0x, g0y, g1x, g1y;
+                buf_ld2(rI, A.vo[im], 0, g0x, g0y);
+                buf_ld2(rI, A.vo[im], ipb, g1x, g1y);
+                G[im][0].x = g0x; G[im][0].y = g0y; G[im][1].x = g1x; G[im][1].y = g1y;
+            }
         };
         auto wblend = [&](auto pc, const WAddr &A) __attribute__((always_inline)) {     // blend the gathered taps of a step -> LDS plane
             constexpr int WP = decltype(pc)::value;
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int im = 0; im < 2; ++im) {
-                    const int sx = A.sx[e][im], sy = A.sy[e][im];
-                    const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
-                    const int dx = ix - min(max(ix, 0), W - 2), dy = iy - min(max(iy, 0), H - 2);
-                    const float fa = (float)(sx & 31) * (1.0f / 32), fb = (float)(sy & 31) * (1.0f / 32);
-                    const float w0 = (1.0f - fb) * (1.0f - fa), w1 = (1.0f - fb) * fa, w2 = fb * (1.0f - fa), w3 = fb * fa;
-                    lk_d2 top = G[e][im][0], bot = G[e][im][1];
-                    if (__builtin_amdgcn_ballot_w64((dx | dy) != 0) != 0) {   // some lane's taps leave the image (wave-uniform, no memory instruction)
-                        const lk_d2 z = {0.0, 0.0};
-                        const lk_d2 t0 = top, t1 = bot;
-                        top = dy == 0 ? t0 : (dy == 1 ? t1 : z);
-                        bot = dy == 0 ? t1 : (dy == -1 ? t0 : z);
-                        const lk_d2 a0 = top, a1 = bot;
-                        top.x = dx == 0 ? a0.x : (dx == 1 ? a0.y : 0.0); top.y = dx == 0 ? a0.y : (dx == -1 ? a0.x : 0.0);
-                        bot.x = dx == 0 ? a1.x : (dx == 1 ? a1.y : 0.0); bot.y = dx == 0 ? a1.y : (dx == -1 ? a1.x : 0.0);
-                    }
-                    s_w[WP][e][im][g] = top.x * (double)w0 + top.y * (double)w1 + bot.x * (double)w2 + bot.y * (double)w3;
+            for (int im = 0; im < 2; ++im) {
+                const int sx = A.sx[im], sy = A.sy[im];
+                const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
+                const int dx = ix - min(max(ix, 0), W - 2), dy = iy - min(max(iy, 0), H - 2);
+                const float fa = (float)(sx & 31) * (1.0f / 32), fb = (float)(sy & 31) * (1.0f / 32);
+                const float w0 = (1.0f - fb) * (1.0f - fa), w1 = (1.0f - fb) * fa, w2 = fb * (1.0f - fa), w3 = fb * fa;
+                lk_d2 top = G[im][0], bot = G[im][1];
+                if (__builtin_amdgcn_ballot_w64((dx | dy) != 0) != 0) {   // some lane's taps leave the image (wave-uniform, no memory instruction)
+                    const lk_d2 z = {0.0, 0.0};
+                    const lk_d2 t0 = top, t1 = bot;
+                    top = dy == 0 ? t0 : (dy == 1 ? t1 : z);
+                    bot = dy == 0 ? t1 : (dy == -1 ? t0 : z);
+                    const lk_d2 a0 = top, a1 = bot;
+                    top.x = dx == 0 ? a0.x : (dx == 1 ? a0.y : 0.0); top.y = dx == 0 ? a0.y : (dx == -1 ? a0.x : 0.0);
+                    bot.x = dx == 0 ? a1.x : (dx == 1 ? a1.y : 0.0); bot.y = dx == 0 ? a1.y : (dx == -1 ? a1.x : 0.0);
                 }
+                s_w[WP][E][im][g] = top.x * (double)w0 + top.y * (double)w1 + bot.x * (double)w2 + bot.y * (double)w3;
+            }
         };
         WAddr cur, nxt;
         {   // prologue: the carried rows and the rotations of W-steps 0 and 1 straight from memory (from step 2 on: F's service)
@@ -464,6 +528,9 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             wstep(std::integral_constant<int, 0>{}, t);
             wstep(std::integral_constant<int, 1>{}, t + 1);
         }
+        };
+        if (widx < 2) wrole(std::integral_constant<int, 0>{});          // (wave-uniform)
+        else wrole(std::integral_constant<int, 1>{});
       }
     } else if (wv >= C::NB + 5) {
         // =========================================================================================
@@ -662,6 +729,9 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // =========================================================================================
         // B waves: one column per lane: window sums -> flow
         // =========================================================================================
+#ifdef LK_SPLIT_PRIO_B
+        __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_B);
+#endif
         const int t = ltid;                          // block column 0 .. TXC-1
         const int x = x0 + t;
         const int xc = min(max(x, 0), W - 1);
@@ -921,7 +991,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             using E1 = std::integral_constant<int, 1>;
             SRow rA, rB;
             double SA[K], SB[K];
-            constexpr bool BOTH = WIN <= (FW ? 11 : LK_SPLIT_BOTH_MAX);                 // bigger rings leave no registers for two rows of taps
+            constexpr bool BOTH = WIN <= LK_SPLIT_BOTH_MAX;                            // bigger rings leave no registers for two rows of taps
             sload(SPc{}, E0{}, rA);
             if constexpr (BOTH) sload(SPc{}, E1{}, rB);
             __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)

@@ -1,6 +1,6 @@
 // lk_w3x1f.h -- warp + single-level LK FUSED for the reference's own 3 x 3 window, ONE column per lane, gathers one row ahead.
 //
-// Same arithmetic, same expression order and same association of the window sums as lk_w3x2f.h (hence the same bits):
+// Same arithmetic and expression order as lk_w3x2.h; the window sums in the reference's own order (lk_device.h sum9_step):
 // every marched row is PRODUCED (incremental cv::pyrUp of the coarse flow, float map, fixed-point bilinear remap of both
 // UN-warped level images, ParallelVideoPyr.cpp:646-703) instead of loaded, the 3 x 3 window is two DPP wave shifts per
 // field, the vertical window three rows in registers.  What differs is the schedule: the two-column kernel needs ~250
@@ -11,7 +11,7 @@
 // Lanes 0 and 1 are the left halo (lane 1's product needs lane 0's pixel), lane 63 the right halo: 61 output columns per
 // single-wave workgroup.
 #pragma once
-#include "lk_w3x2f.h"
+#include "lk_w3x2.h"
 
 namespace lk {
 
@@ -36,11 +36,9 @@ __global__ __launch_bounds__(64, 3) void lk_w3x1f_kernel(LKArgs a)
     const int yy0 = y0 - R;
     const float xf = (float)xc;
 
-    double ring[WIN][5];                                     // the last three rows' horizontal sums (slot = marched row mod 3)
+    Sum9 win9[5];                                            // partial window sums in the reference's order (lk_device.h sum9_step)
 #pragma unroll
-    for (int q = 0; q < WIN; ++q)
-#pragma unroll
-        for (int f = 0; f < 5; ++f) ring[q][f] = 0.0;
+    for (int f = 0; f < 5; ++f) win9[f].a = win9[f].b = 0.0;
 
     // ---- coarse flow: descriptors, horizontal weights of the column ----
     const int cpub = (int)a.cu.pitch * 8, cpvb = (int)a.cv.pitch * 8;
@@ -177,10 +175,8 @@ __global__ __launch_bounds__(64, 3) void lk_w3x1f_kernel(LKArgs a)
         double S[5];
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
-            const double h = (dpp_wave_shr1(p[f]) + p[f]) + dpp_wave_shl1(p[f]);   // (left + centre) + right
-            // three rows, summed directly in one fixed order, (row i-2 + row i-1) + row i (lk_w3x2f.h)
-            S[f] = (ring[(K + 1) % 3][f] + ring[(K + 2) % 3][f]) + h;
-            ring[K][f] = h;
+            // get_Sum9's own order: nine sequential additions, row-major (the window of output row yy - 1 ends with this row)
+            S[f] = sum9_step(win9[f], dpp_wave_shr1(p[f]), p[f], dpp_wave_shl1(p[f]));
         }
         p1 = c1; p2 = c2; lp1 = lc1; lp2 = lc2;
         c1 = n1; c2 = n2;

@@ -7,8 +7,8 @@
 //     lane's second pixel (DPP wave shift; at image column 0 it is the reflected column 1 = the lane's own second
 //     pixel), so there are no tap loads at all;
 //   * the 3-tap horizontal window of both columns comes from the lane's own two products plus one DPP shift each way
-//     (no LDS, no barrier); summation order (left + centre) + right, identical to the one-column kernel, hence
-//     bit-identical results;
+//     (no LDS, no barrier); the nine terms of a window are added in the reference's own row-major order
+//     (lk_device.h sum9_step), as in the one-column kernels: bit-identical results;
 //   * both columns share one coarse column j = xa / 2 of the "+= pyrUp" term: three coarse taps per row serve both
 //     (u plane on even output rows, v plane on odd ones -- the TAP3 scheme of lk_march3.h);
 //   * flows leave as 16-byte stores.
@@ -64,11 +64,9 @@ __global__ __launch_bounds__(64, 2) void lk_w3x2_kernel(LKArgs a)
     const int nmarch = (y1 - y0) + 2 * R;
     const int yy0 = y0 - R;
 
-    double ringA[WIN][5], ringB[WIN][5];       // the last three rows' horizontal sums (slot = marched row mod 3)
+    Sum9 w9A[5], w9B[5];                       // partial window sums of the two columns, reference order (lk_device.h sum9_step)
 #pragma unroll
-    for (int q = 0; q < WIN; ++q)
-#pragma unroll
-        for (int f = 0; f < 5; ++f) ringA[q][f] = ringB[q][f] = 0.0;
+    for (int f = 0; f < 5; ++f) w9A[f].a = w9A[f].b = w9B[f].a = w9B[f].b = 0.0;
 
     auto img_row_off = [&](int yy) {
         int rr = yy < 0 ? -yy : yy;
@@ -163,13 +161,10 @@ __global__ __launch_bounds__(64, 2) void lk_w3x2_kernel(LKArgs a)
         double SA[5], SB[5];
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
-            const double hA = (dpp_wave_shr1(pB[f]) + pA[f]) + pB[f];   // (left + centre) + right
-            const double hB = (pA[f] + pB[f]) + dpp_wave_shl1(pA[f]);
-            // three rows, summed directly in one fixed order, (row i-2 + row i-1) + row i: independent of where the
-            // strip starts, so a sharded / differently batched run reproduces the same bits
-            SA[f] = (ringA[(K + 1) % 3][f] + ringA[(K + 2) % 3][f]) + hA;
-            SB[f] = (ringB[(K + 1) % 3][f] + ringB[(K + 2) % 3][f]) + hB;
-            ringA[K][f] = hA; ringB[K][f] = hB;
+            // get_Sum9's own order (nine sequential additions, row-major): independent of where the strip starts, so a
+            // sharded / differently batched run reproduces the same bits
+            SA[f] = sum9_step(w9A[f], dpp_wave_shr1(pB[f]), pA[f], pB[f]);
+            SB[f] = sum9_step(w9B[f], pA[f], pB[f], dpp_wave_shl1(pA[f]));
         }
         // rotate: the only wait for the row prefetched PF iterations ago
         p1a = c1a; p1b = c1b; p2a = c2a; p2b = c2b; lp1 = lc1; lp2 = lc2;

@@ -38,11 +38,9 @@ __global__ __launch_bounds__(64, 2) void lk_w3x2f_kernel(LKArgs a)
     const int yy0 = y0 - R;
     const float xfa = (float)xc, xfb = (float)(xc + 1);
 
-    double ringA[WIN][5], ringB[WIN][5];       // the last three rows' horizontal sums (slot = marched row mod 3)
+    Sum9 w9A[5], w9B[5];                       // partial window sums of the two columns, reference order (lk_device.h sum9_step)
 #pragma unroll
-    for (int q = 0; q < WIN; ++q)
-#pragma unroll
-        for (int f = 0; f < 5; ++f) ringA[q][f] = ringB[q][f] = 0.0;
+    for (int f = 0; f < 5; ++f) w9A[f].a = w9A[f].b = w9B[f].a = w9B[f].b = 0.0;
 
     // ---- coarse flow: descriptors, per-column horizontal weights, carried rows s(i-1), s(i), s(i+1) of row yw ----
     const int cpub = (int)a.cu.pitch * 8, cpvb = (int)a.cv.pitch * 8;
@@ -204,13 +202,8 @@ __global__ __launch_bounds__(64, 2) void lk_w3x2f_kernel(LKArgs a)
         double SA[5], SB[5];
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
-            const double hA = (dpp_wave_shr1(pB[f]) + pA[f]) + pB[f];   // (left + centre) + right
-            const double hB = (pA[f] + pB[f]) + dpp_wave_shl1(pA[f]);
-            // three rows, summed directly in one fixed order, (row i-2 + row i-1) + row i: independent of where the
-            // strip starts, so a sharded / differently batched run reproduces the same bits
-            SA[f] = (ringA[(K + 1) % 3][f] + ringA[(K + 2) % 3][f]) + hA;
-            SB[f] = (ringB[(K + 1) % 3][f] + ringB[(K + 2) % 3][f]) + hB;
-            ringA[K][f] = hA; ringB[K][f] = hB;
+            SA[f] = sum9_step(w9A[f], dpp_wave_shr1(pB[f]), pA[f], pB[f]);   // get_Sum9's own order (lk_device.h)
+            SB[f] = sum9_step(w9B[f], pA[f], pB[f], dpp_wave_shl1(pA[f]));
         }
         p1a = c1a; p1b = c1b; p2a = c2a; p2b = c2b; lp1 = lc1; lp2 = lc2;
         c1a = n1a; c1b = n1b; c2a = n2a; c2b = n2b;

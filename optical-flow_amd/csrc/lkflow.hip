@@ -23,12 +23,22 @@
 #include "lk_kernels.h"
 #include "lk_march3.h"
 #include "lk_split.h"
-#include "lk_batch.h"
 #include "lk_w3x2.h"
-#include "lk_w3x2f.h"
 #include "lk_w3x1f.h"
+// Kernels that were measured SLOWER than the shipped path and are kept as records: the batch-synchronous
+// kernel (lk_batch.h, LKFLOW_OPT_LK_BATCH) and the two-column fused 3 x 3 kernel (lk_w3x2f.h).  Only a -DLKFLOW_EXPERIMENTAL
+// build (tools/build_variant.sh) carries them; the default library answers LKFLOW_E_ARG to their options.
+#ifdef LKFLOW_EXPERIMENTAL
+#include "lk_batch.h"
+#include "lk_w3x2f.h"
+#endif
 
-#define LKFLOW_VERSION_STR "lkflow-mi355x 0.3 (gfx950)"
+// the digest of the kernel sources this library was built from (__graft_entry__.csrc_digest(), passed by build_hip()): bench.py
+// and tools/pmc_summary.py attach committed profile numbers only to a LOADED library that carries the digest they were measured on
+#ifndef LKFLOW_CSRC_SHA
+#define LKFLOW_CSRC_SHA "unstamped"
+#endif
+#define LKFLOW_VERSION_STR "lkflow-mi355x 0.4 (gfx950) src:" LKFLOW_CSRC_SHA
 
 namespace {
 
@@ -405,17 +415,19 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s, i
     a.th = th;
     a.gx = gx; a.gy = (a.H + th - 1) / th;
     if ((long long)a.gx * a.gy * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
-    a.nmain = 0; a.nbb = 0;
+    // the frame of clipped-window pixels and the outermost ring (its warped taps are made on the fly, lk_border_pixel<., true>):
+    // trailing workgroups of the same launch, as in the unfused kernel
+    const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
+    const long long nfp = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
+    if (nfp + 2 * C::NT >= 0x7fffffffLL) return LKFLOW_E_ARG;
+    const long long nbb = (nfp + C::NT - 1) / C::NT;
+    dim3 grid((unsigned)(a.gx * a.gy * pairs));
+    if ((long long)grid.x + nbb * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
+    a.nmain = grid.x; a.nbb = (unsigned)nbb;
+    static const int no_border = knob("LKFLOW_ABL_NO_BORDER", 0);   // (timing-only ablation of a debug-knob build: results wrong)
+    if (!no_border) grid.x += (unsigned)(nbb * pairs);
     ProfScope ps(ctx, LKFLOW_STAGE_LK, level, s);    // (opened only once the shape is taken: a fallback leaves no empty record)
-    BorderFork bf(ctx, s);
-    {   // the frame of clipped-window pixels and the outermost ring (its warped taps are made on the fly)
-        const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
-        const long long n = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
-        if (n + 512 >= 0x7fffffffLL) return LKFLOW_E_ARG;
-        hipLaunchKernelGGL((lk::lk_border_kernel<true, true>), dim3((unsigned)((n + 255) / 256), pairs), dim3(256), 0, bf.bs, a, WIN);
-    }
-    hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true, true>), dim3((unsigned)(a.gx * a.gy * pairs)), dim3(C::NT), 0, s, a);
-    if (!bf.join()) { hip_ok(ctx, hipGetLastError(), "frame kernel join"); return LKFLOW_E_HIP; }
+    hipLaunchKernelGGL((lk::lk_split_kernel<WIN, K, true, true>), grid, dim3(C::NT), 0, s, a);
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }
@@ -473,6 +485,7 @@ int launch_split(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, i
     }
 }
 
+#ifdef LKFLOW_EXPERIMENTAL
 // Batch-synchronous kernel (lk_batch.h): 8 identical waves, 8 marched rows per phase pair; fw: a.i1 / a.i2 are the
 // UN-warped level images and the warp of the level runs inside the kernel.  LK_NOT_TAKEN: shape not taken.
 template <int WIN>
@@ -532,6 +545,11 @@ int launch_batch(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, bool fw, int
     }
 }
 
+#else
+inline bool batch_applies(const lkflow_ctx *, int, int, int) { return false; }
+inline int launch_batch(lkflow_ctx *, const lk::LKArgs &, bool, bool, int, int, hipStream_t, int, int) { return LK_NOT_TAKEN; }
+#endif
+
 // 3 x 3 windows on even-width levels: two columns per lane (lk_w3x2.h)
 int launch_w3x2(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
 {
@@ -555,7 +573,7 @@ int launch_w3x2(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream
 // warp + LK fused for 3 x 3 windows (lk_w3x2f.h): a.i1 / a.i2 are the UN-warped level images
 bool fused_w3_applies(const lkflow_ctx *ctx, int win, int W, int H)
 {
-    static const bool off = knob("LKFLOW_NO_W3_FUSED", 0) || knob("LKFLOW_NO_W3X2", 0);
+    static const bool off = (knob("LKFLOW_NO_W3_FUSED", 0) | knob("LKFLOW_NO_W3X2", 0)) != 0;
     return !off && ctx->impl == 0 && win == 3 && W >= 2 && !(W & 1) && !(H & 1);
 }
 #ifndef LKFLOW_W3_ONE_COLUMN
@@ -563,9 +581,15 @@ bool fused_w3_applies(const lkflow_ctx *ctx, int win, int W, int H)
 #endif
 int launch_w3x2f(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
 {
+#ifdef LKFLOW_EXPERIMENTAL
     static const int one_col = knob("LKFLOW_W3_ONE_COLUMN", LKFLOW_W3_ONE_COLUMN);   // A/B
     const int xo = one_col ? lk::W3X1_XO : lk::W3X2_XO;
     const int bpc = one_col ? blocks_per_cu(ctx, lk::lk_w3x1f_kernel, 64) : blocks_per_cu(ctx, lk::lk_w3x2f_kernel, 64);
+#else
+    constexpr int one_col = 1;
+    const int xo = lk::W3X1_XO;
+    const int bpc = blocks_per_cu(ctx, lk::lk_w3x1f_kernel, 64);
+#endif
     const int gx = (a.W + xo - 1) / xo;
     int th = ctx->tile_rows > 0 ? ctx->tile_rows : pick_tile_rows(a.H, 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
     if (th > a.H) th = a.H;
@@ -577,23 +601,30 @@ int launch_w3x2f(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
     }
     a.th = th;
     if (one_col) hipLaunchKernelGGL(lk::lk_w3x1f_kernel, dim3(gx, (a.H + th - 1) / th, pairs), dim3(64), 0, s, a);
+#ifdef LKFLOW_EXPERIMENTAL
     else hipLaunchKernelGGL(lk::lk_w3x2f_kernel, dim3(gx, (a.H + th - 1) / th, pairs), dim3(64), 0, s, a);
+#endif
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }
 
-template <int TX>
+// One-role kernel (lk_march3.h) for the shapes the wave-specialised kernel does not take: odd or tiny levels -- only ever
+// the coarsest levels of a pyramid, where the time is negligible -- so every window is compiled for ONE block width:
+// 128-column blocks (2 waves per barrier, ~10 % faster per thread-column than 256-column ones) up to 15 x 15, 256-column
+// blocks above (the 2R halo columns would eat a 128-column block).  Results do not depend on the block width (the pair
+// sums of a window are anchored to the image column's parity).  3 x 3 never comes here (launch_lk).
+constexpr int lk3_block_width(int win) { return win <= 15 ? 128 : 256; }
 int launch_lk3(lkflow_ctx *ctx, const lk::LKArgs &a, bool has_up, int pairs, int win, hipStream_t s)
 {
     switch (win) {
-#define LK_CASE(WN) case WN: return launch_lk3_win<WN, TX>(ctx, a, has_up, pairs, s);
+#define LK_CASE(WN) case WN: return launch_lk3_win<WN, lk3_block_width(WN)>(ctx, a, has_up, pairs, s);
 #ifdef LKFLOW_FAST_BUILD   /* A/B experiment builds: only the windows the goldens / headline use */
-        LK_CASE(3) LK_CASE(5) LK_CASE(9) LK_CASE(13) LK_CASE(15) LK_CASE(21)
+        LK_CASE(5) LK_CASE(9) LK_CASE(13) LK_CASE(15) LK_CASE(21)
 #ifdef LKFLOW_FAST_WINS_EXTRA
         LK_CASE(23) LK_CASE(25) LK_CASE(27) LK_CASE(29) LK_CASE(31)
 #endif
 #else
-        LK_CASE(3) LK_CASE(5) LK_CASE(7) LK_CASE(9) LK_CASE(11) LK_CASE(13) LK_CASE(15) LK_CASE(17)
+        LK_CASE(5) LK_CASE(7) LK_CASE(9) LK_CASE(11) LK_CASE(13) LK_CASE(15) LK_CASE(17)
         LK_CASE(19) LK_CASE(21) LK_CASE(23) LK_CASE(25) LK_CASE(27) LK_CASE(29) LK_CASE(31)
 #endif
 #undef LK_CASE
@@ -612,31 +643,16 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
         return LKFLOW_OK;
     }
     if (ctx->impl == 0) {
-#ifdef LK3_TX
-        int rc = launch_lk3<LK3_TX>(ctx, a, has_up, pairs, win, s);
-#else
-        // Block width: 128-column blocks (2 waves per barrier) run ~10 % faster per thread-column than
-        // 256-column ones, but lose 2R of every 128 columns to the halo; take them when the image width
-        // tiles almost as well (1920 wide, w15: 17 x 128 = 2176 vs 8 x 256 = 2048 thread-columns).
-        const int R = win / 2;
-        const long long c128 = (long long)((a.W + (128 - 2 * R) - 1) / (128 - 2 * R)) * 128;
-        const long long c256 = (long long)((a.W + (256 - 2 * R) - 1) / (256 - 2 * R)) * 256;
-        bool use128 = win <= 15 && c128 * 100 <= c256 * 108;
-        { static const int e = knob("LKFLOW_LK_TX", 0);
-          if (e == 128) use128 = true; else if (e == 256) use128 = false; }
         int rc;
-        static const bool no_w3 = knob("LKFLOW_NO_W3_DPP", 0) != 0;
         static const bool no_x2 = knob("LKFLOW_NO_W3X2", 0) != 0;
         if (win == 3 && !no_x2 && a.W >= 2 && !(a.W & 1)) rc = launch_w3x2(ctx, a, has_up, pairs, s);   // 2 columns per lane
-        else if (win == 3 && !no_w3) rc = launch_lk3_win<3, 64>(ctx, a, has_up, pairs, s);   // barrier-free DPP kernel
+        else if (win == 3) rc = launch_lk3_win<3, 64>(ctx, a, has_up, pairs, s);   // barrier-free DPP kernel
         else {
             rc = batch_applies(ctx, win, a.W, a.H) ? launch_batch(ctx, a, has_up, false, pairs, win, s, -1, 0) : LK_NOT_TAKEN;
             if (rc == LK_NOT_TAKEN)
                 rc = split_applies(win, a.W, a.H) ? launch_split(ctx, a, has_up, pairs, win, s) : LK_NOT_TAKEN;
-            if (rc == LK_NOT_TAKEN)
-                rc = use128 ? launch_lk3<128>(ctx, a, has_up, pairs, win, s) : launch_lk3<256>(ctx, a, has_up, pairs, win, s);
+            if (rc == LK_NOT_TAKEN) rc = launch_lk3(ctx, a, has_up, pairs, win, s);
         }
-#endif
         if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
         return LKFLOW_OK;
@@ -722,18 +738,15 @@ int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok,
     int rc = check_win(win);
     if (rc) return rc;
     const char *up = has_up ? "true" : "false";
-    static const bool no_fused = knob("LKFLOW_NO_W3_FUSED", 0) || knob("LKFLOW_NO_W3X2", 0);
-    static const bool no_x2 = knob("LKFLOW_NO_W3X2", 0) != 0, no_w3 = knob("LKFLOW_NO_W3_DPP", 0) != 0;
+    static const bool no_fused = (knob("LKFLOW_NO_W3_FUSED", 0) | knob("LKFLOW_NO_W3X2", 0)) != 0;
+    static const bool no_x2 = knob("LKFLOW_NO_W3X2", 0) != 0;
     if (win == 3 && has_up && fused_ok && !no_fused && cols >= 2 && !(cols & 1) && !(rows & 1))
-        snprintf(buf, n, knob("LKFLOW_W3_ONE_COLUMN", LKFLOW_W3_ONE_COLUMN) ? "lk::lk_w3x1f_kernel" : "lk::lk_w3x2f_kernel");
+        snprintf(buf, n, "%s", knob("LKFLOW_W3_ONE_COLUMN", LKFLOW_W3_ONE_COLUMN) ? "lk::lk_w3x1f_kernel" : "lk::lk_w3x2f_kernel");
     else if (win == 3 && !no_x2 && cols >= 2 && !(cols & 1)) snprintf(buf, n, "lk::lk_w3x2_kernel<%s>", up);
-    else if (win == 3 && !no_w3) snprintf(buf, n, "lk::lk_march3_kernel<3, 64, %s>", up);
+    else if (win == 3) snprintf(buf, n, "lk::lk_march3_kernel<3, 64, %s>", up);
     else if (split_applies(win, cols, rows)) snprintf(buf, n, "lk::lk_split_kernel<%d, 2, %s, false>", win, up);   // (..., true> with LKFLOW_OPT_FUSE_WARP)
     else {
-        const int R = win / 2;
-        const long long c128 = (long long)((cols + (128 - 2 * R) - 1) / (128 - 2 * R)) * 128;
-        const long long c256 = (long long)((cols + (256 - 2 * R) - 1) / (256 - 2 * R)) * 256;
-        snprintf(buf, n, "lk::lk_march3_kernel<%d, %d, %s>", win, (win <= 15 && c128 * 100 <= c256 * 108) ? 128 : 256, up);
+        snprintf(buf, n, "lk::lk_march3_kernel<%d, %d, %s>", win, lk3_block_width(win), up);
     }
     return LKFLOW_OK;
 }
@@ -790,9 +803,13 @@ int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value)
             ctx->fuse_warp = value;
             return LKFLOW_OK;
         case LKFLOW_OPT_LK_BATCH:
+#ifdef LKFLOW_EXPERIMENTAL
             if (value < 0 || value > 1) return LKFLOW_E_ARG;
             ctx->lk_batch = value;
             return LKFLOW_OK;
+#else
+            return value == 0 ? LKFLOW_OK : LKFLOW_E_ARG;        // the kernel is not in this build (lkflow.h)
+#endif
         case LKFLOW_OPT_TILE_ROWS:
             if (value < 0 || value > 4096) return LKFLOW_E_ARG;
             ctx->tile_rows = value;
@@ -1396,3 +1413,5 @@ int lkflow_flow_centroid_f64_dev(lkflow_ctx *ctx, const double *U, const double 
 }
 
 }  // extern "C"
+
+#include "lk_stream.h"

@@ -29,6 +29,7 @@ LKFLOW_E_HIP = -4
 LKFLOW_E_NOMEM = -5
 LKFLOW_E_NODEVICE = -6
 LKFLOW_MUTATE_INPUTS = 1
+LKFLOW_STREAM_KEEP_FLOW = 1
 LKFLOW_MAX_WIN = 31
 LKFLOW_OPT_IMPL = 1
 LKFLOW_OPT_TILE_ROWS = 2
@@ -81,6 +82,14 @@ SIGNATURES = {
     "lkflow_edge_map_u8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _i, _vp, _sz, _sz, _vp]),
     "lkflow_diff_edge_map_u8_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _i, _vp, _sz, _sz, _vp]),
     "lkflow_flow_centroid_f64_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _vp, _vp]),
+    "lkflow_stream_create": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i, _i, _i, _u]),
+    "lkflow_stream_destroy": (None, [_vp]),
+    "lkflow_stream_set_budget": (_i, [_vp, _sz]),
+    "lkflow_stream_push_u8": (_i, [_vp, _vp, _i, _sz, _sz, _d]),
+    "lkflow_stream_centroids": (_i, [_vp, _vp, _i]),
+    "lkflow_stream_flow": (_i, [_vp, _i, _vp, _vp, _sz]),
+    "lkflow_stream_block": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "lkflow_stream_last_error": (ctypes.c_char_p, [_vp]),
 }
 
 _LIB = None
@@ -524,6 +533,70 @@ class Context:
                                                      float(thresh), out.data_ptr(),
                                                      _stream_ptr(stream)))
         return out
+
+
+# ---- the C-ABI frame-queue engine over a device list (lkflow_stream_*, include/lkflow.h) ---------
+class StreamEngine:
+    """lkflow_stream: one worker thread + context + stream per entry of `devices` (in ONE process); push() takes a
+    [F, H, W] uint8 HOST array (numpy), centroids() waits and returns the [F-1, 3] rows, flow(p) one pair's U, V."""
+
+    def __init__(self, devices, rows, cols, levels, win, keep_flow=False):
+        arr = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        h = _vp()
+        rc = lib().lkflow_stream_create(ctypes.byref(h), arr, len(devices), int(rows), int(cols), int(levels), int(win),
+                                        LKFLOW_STREAM_KEEP_FLOW if keep_flow else 0)
+        if rc:
+            raise LKFlowError(rc)
+        self._h, self.rows, self.cols, self._frames, self.n_pairs = h, rows, cols, None, 0
+
+    def close(self):
+        if self._h:
+            lib().lkflow_stream_destroy(self._h)
+            self._h = None
+            self._frames = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc:
+            raise LKFlowError(rc, lib().lkflow_stream_last_error(self._h).decode())
+
+    def set_budget(self, nbytes):
+        self._chk(lib().lkflow_stream_set_budget(self._h, int(nbytes)))
+
+    def push(self, frames_u8, thresh=20.0):
+        import numpy as np
+        f = frames_u8
+        assert isinstance(f, np.ndarray) and f.dtype == np.uint8 and f.ndim == 3 and f.strides[2] == 1
+        assert f.shape[1:] == (self.rows, self.cols)
+        self._frames = f                                     # must stay alive until the push has completed
+        self.n_pairs = f.shape[0] - 1
+        self._chk(lib().lkflow_stream_push_u8(self._h, f.ctypes.data, f.shape[0], f.strides[0], f.strides[1], float(thresh)))
+
+    def centroids(self):
+        import numpy as np
+        out = np.empty((self.n_pairs, 3), dtype=np.float64)
+        self._chk(lib().lkflow_stream_centroids(self._h, out.ctypes.data, self.n_pairs))
+        return out
+
+    def flow(self, pair):
+        import numpy as np
+        U = np.empty((self.rows, self.cols)); V = np.empty_like(U)
+        self._chk(lib().lkflow_stream_flow(self._h, int(pair), U.ctypes.data, V.ctypes.data, U.strides[0]))
+        return U, V
+
+
+def stream_block(n_frames, n_devices, k):
+    """lkflow_stream_block: (first_frame, n_frames_local) of list entry k -- the C side of shard_pairs()."""
+    a, b = _i(), _i()
+    rc = lib().lkflow_stream_block(int(n_frames), int(n_devices), int(k), ctypes.byref(a), ctypes.byref(b))
+    if rc:
+        raise LKFlowError(rc)
+    return a.value, b.value
 
 
 # ---- frame-pair sharding of a video stream over ranks (SURVEY.md 8(e)) ---------------------------

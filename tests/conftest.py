@@ -42,12 +42,12 @@ def goldens():
 
 @pytest.fixture(scope="session")
 def lkflow():
-    """The ctypes binding; builds liblkflow.so first if it is missing (the .so is git-ignored, so a fresh
+    """The ctypes binding; builds liblkflow.so first if it is missing or stale (the .so is git-ignored, so a fresh
     checkout has none -- hipcc cross-compiles gfx950 without a GPU, about a minute)."""
     import lkflow_amd
-    if not os.path.exists(lkflow_amd.LIB_PATH):
+    if not os.environ.get("LKFLOW_LIB"):
         import __graft_entry__
-        __graft_entry__.build_hip()
+        __graft_entry__.build_hip()          # no-op unless the library is missing or was built from other sources (digest)
     return lkflow_amd
 
 

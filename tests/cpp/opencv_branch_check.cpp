@@ -52,6 +52,40 @@ int main(int argc, char **argv)
         try { cv::Mat c(H, W + 2, CV_64FC1), uu, vv; lkflow::computeFlow(a, c, uu, vv, 1, 3); } catch (const std::invalid_argument &) { threw = true; }
         std::printf("max |d flow| = %g, max |d mutated inputs| = %g, size mismatch throws: %d\n", d, dm, (int)threw);
         if (d != 0.0 || dm != 0.0 || !threw) return 1;
+        // Two back-to-back enqueue() calls WITHOUT a wait between them (the C ABI allows it: the second waits for the first),
+        // unequal steps, LKFLOW_MUTATE_INPUTS, two different sizes (the engine's staging buffer must grow under the second
+        // call), pageable and page-locked host buffers: flow and overwritten inputs must equal the synchronous calls'.
+        for (int pin = 0; pin < 2; ++pin) {
+            const int H2 = 96, W2 = 160;
+            cv::Mat c1(H, W, CV_64FC1), c2(H, W, CV_64FC1, (size_t)(W + 7) * 8);                 // small pair, unequal steps
+            cv::Mat e1(H2, W2, CV_64FC1), e2(H2, W2, CV_64FC1, (size_t)(W2 + 3) * 8);             // larger pair, unequal steps
+            cv::Mat r1(H, W, CV_64FC1), r2(H, W, CV_64FC1), s1(H2, W2, CV_64FC1), s2(H2, W2, CV_64FC1);   // continuous twins
+            fill(c1, 5); fill(r1, 5); fill(r2, 6); fill(e1, 7); fill(s1, 7); fill(s2, 8);
+            for (int y = 0; y < H; ++y) std::memcpy(c2.ptr<double>(y), r2.ptr<double>(y), W * 8);
+            for (int y = 0; y < H2; ++y) std::memcpy(e2.ptr<double>(y), s2.ptr<double>(y), W2 * 8);
+            cv::Mat ur, vr, us, vs, uc, vc, ue, ve;
+            lkflow::coarseToFineEstimation(r1, r2, ur, vr, 3);
+            lkflow::coarseToFineEstimation(s1, s2, us, vs, 3);
+            {
+                lkflow::Engine eng(0);
+                eng.pinHostBuffers(pin != 0);
+                eng.enqueue(c1, c2, uc, vc, 3, 3, LKFLOW_MUTATE_INPUTS);
+                eng.enqueue(e1, e2, ue, ve, 3, 3, LKFLOW_MUTATE_INPUTS);     // no wait() in between
+                eng.wait();
+                eng.pinHostBuffers(false);
+            }
+            double da = 0.0;
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x)
+                    da = std::fmax(da, std::fabs(uc.at<double>(y, x) - ur.at<double>(y, x)) + std::fabs(vc.at<double>(y, x) - vr.at<double>(y, x)) +
+                                           std::fabs(c1.at<double>(y, x) - r1.at<double>(y, x)) + std::fabs(c2.at<double>(y, x) - r2.at<double>(y, x)));
+            for (int y = 0; y < H2; ++y)
+                for (int x = 0; x < W2; ++x)
+                    da = std::fmax(da, std::fabs(ue.at<double>(y, x) - us.at<double>(y, x)) + std::fabs(ve.at<double>(y, x) - vs.at<double>(y, x)) +
+                                           std::fabs(e1.at<double>(y, x) - s1.at<double>(y, x)) + std::fabs(e2.at<double>(y, x) - s2.at<double>(y, x)));
+            std::printf("back-to-back enqueue (pinned %d): max |d| = %g\n", pin, da);
+            if (da != 0.0) return 1;
+        }
         std::printf("ok\n");
         return 0;
     } catch (const std::exception &e) {

@@ -63,3 +63,47 @@ def test_missing_library_raises(lkflow, monkeypatch):
     monkeypatch.setattr(lkflow, "LIB_PATH", os.path.join(os.path.dirname(lkflow.LIB_PATH), "nope.so"))
     with pytest.raises(ImportError):
         lkflow.lib()
+
+
+def test_stream_block_is_the_python_partition_rule(lkflow):
+    """lkflow_stream_block (the C-ABI frame-queue engine's partition, include/lkflow.h) == lkflow_amd.shard_pairs
+    (contiguous blocks of the F - 1 pairs, one-frame overlap, sizes differing by at most one)."""
+    for F in list(range(0, 40)) + [245, 256, 1000]:
+        for n in (1, 2, 3, 7, 8, 16):
+            covered = 0
+            for k in range(n):
+                first, nl = lkflow.stream_block(F, n, k)
+                assert (first, nl) == lkflow.shard_pairs(F, n, k)
+                if nl:
+                    assert first == covered
+                    covered += nl - 1
+            assert covered == max(F - 1, 0)
+
+
+def test_stream_engine_argument_errors_need_no_gpu(lkflow):
+    L = lkflow.lib()
+    h = ctypes.c_void_p()
+    devs = (ctypes.c_int * 1)(0)
+    assert L.lkflow_stream_create(None, devs, 1, 8, 8, 1, 3, 0) == lkflow.LKFLOW_E_ARG
+    assert L.lkflow_stream_create(ctypes.byref(h), None, 1, 8, 8, 1, 3, 0) == lkflow.LKFLOW_E_ARG
+    assert L.lkflow_stream_create(ctypes.byref(h), devs, 0, 8, 8, 1, 3, 0) == lkflow.LKFLOW_E_ARG
+    assert L.lkflow_stream_create(ctypes.byref(h), devs, 1, 8, 8, 9, 3, 0) == lkflow.LKFLOW_E_LEVELS
+    assert L.lkflow_stream_create(ctypes.byref(h), devs, 1, 8, 8, 1, 4, 0) == lkflow.LKFLOW_E_WIN
+    assert L.lkflow_stream_create(ctypes.byref(h), devs, 1, 8, 8, 1, 3, 2) == lkflow.LKFLOW_E_ARG
+    assert L.lkflow_stream_push_u8(None, None, 2, 64, 8, 1.0) == lkflow.LKFLOW_E_ARG
+    assert L.lkflow_stream_centroids(None, None, 1) == lkflow.LKFLOW_E_ARG
+    L.lkflow_stream_destroy(None)
+    import torch
+    if not torch.cuda.is_available():                        # no device: the engine fails loudly, like a context
+        assert L.lkflow_stream_create(ctypes.byref(h), devs, 1, 8, 8, 1, 3, 0) in (lkflow.LKFLOW_E_NODEVICE, lkflow.LKFLOW_E_HIP)
+        assert not h.value
+
+
+def test_library_carries_the_digest_of_its_sources(lkflow):
+    """the committed profile numbers belong to a source digest; the LOADED library says which sources it was built
+    from (lkflow_version() ends in src:<digest>), so a stale or variant .so cannot borrow them."""
+    import __graft_entry__ as ge
+    v = lkflow.lib().lkflow_version().decode()
+    assert "src:" in v
+    if not os.environ.get("LKFLOW_LIB"):
+        assert v.rsplit("src:", 1)[1] == ge.lib_digest() == ge.csrc_digest(), "liblkflow.so is stale: python __graft_entry__.py build"

@@ -30,20 +30,22 @@ def test_usable_cores_is_what_the_scheduler_allows():
 
 
 def test_committed_pmc_traffic_is_usable_by_bench():
-    """roofline.traffic comes from profiles/pmc_traffic.json: the committed file is tagged with the headline workload and
-    with the digest of the kernel sources it was measured on.  On matching code it must give a per-launch figure between
-    the algorithmic bytes and twice that (aprons, halos); on any other code -- or workload -- bench.py must report null
-    rather than a stale number."""
+    """roofline.traffic / rocprof_avg_launch_ms come from profiles/pmc_traffic.json: one record per workload, each tagged with
+    the digest of the kernel sources it was measured on.  On matching code (tree AND loaded library) the headline record must
+    give a per-launch figure between the algorithmic bytes and twice that (aprons, halos); on any other code -- or workload --
+    bench.py must report null rather than a stale number."""
     import json
     import bench
     cols, rows, levels, win, pairs = bench.CONFIGS["1080p"]
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-        rec = json.load(fh)
+        top = json.load(fh)
+    assert "workloads" in top
+    rec = top["workloads"].get(f"{cols}x{rows}x{pairs}")
+    assert rec, "no headline workload in profiles/pmc_traffic.json"
     names = [k for k in rec if k.startswith("lk::lk_") and ", true" in k]     # HAS_UP instantiations
-    assert names, "no level-0 LK kernel in profiles/pmc_traffic.json"
-    assert rec.get("_workload") == f"{cols}x{rows}x{pairs}"
+    assert names, "no level-0 LK kernel in the headline record"
     ts = [bench.measured_traffic(k, cols, rows, pairs) for k in names]
-    if rec.get("_csrc_sha") == bench.csrc_digest():
+    if rec.get("_csrc_sha") == bench.csrc_digest() == bench.loaded_lib_digest():
         sys.path.insert(0, os.path.join(ROOT, "optical-flow_amd"))
         import lkflow_amd                                    # the name bench.py looks up is the one rocprofv3 printed
         assert lkflow_amd.lk_kernel_name(rows, cols, win, has_up=True) in names
@@ -57,14 +59,22 @@ def test_committed_pmc_traffic_is_usable_by_bench():
 
 def test_csrc_digest_follows_the_kernel_sources(tmp_path, monkeypatch):
     import bench
+    import __graft_entry__ as ge
     d0 = bench.csrc_digest()
-    assert len(d0) == 16 and d0 == bench.csrc_digest()
+    assert len(d0) == 16 and d0 == bench.csrc_digest() == ge.csrc_digest()
     fake = tmp_path / "repo"
     (fake / "optical-flow_amd" / "csrc").mkdir(parents=True)
     (fake / "include").mkdir()
     (fake / "optical-flow_amd" / "csrc" / "k.h").write_text("a")
     (fake / "include" / "lkflow.h").write_text("h")
-    monkeypatch.setattr(bench, "ROOT", str(fake))
+    monkeypatch.setattr(ge, "ROOT", str(fake))
+    monkeypatch.setattr(ge, "CSRC", str(fake / "optical-flow_amd" / "csrc"))
     d1 = bench.csrc_digest()
     (fake / "optical-flow_amd" / "csrc" / "k.h").write_text("b")
     assert bench.csrc_digest() != d1 and d1 != d0
+    # a library says which sources it was built from; one without the stamp (or a missing one) says nothing
+    lib = tmp_path / "lib.so"
+    lib.write_bytes(b"\x00junk lkflow-mi355x 0.4 (gfx950) src:0123456789abcdef\x00more")
+    assert ge.lib_digest(str(lib)) == "0123456789abcdef"
+    lib.write_bytes(b"lkflow-mi355x 0.4 (gfx950) src:unstamped")
+    assert ge.lib_digest(str(lib)) is None and ge.lib_digest(str(tmp_path / "none.so")) is None

@@ -72,3 +72,29 @@ def test_cv_mat_call_site_with_unequal_steps(tmp_path):
     exe = _build_opencv_branch(tmp_path)
     r = subprocess.run([exe, "run"], capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def _build_stream_check(tmp_path):
+    exe = str(tmp_path / "stream_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "stream_check.cpp"),
+                           "-o", exe, "-L", PKG, "-llkflow", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{PKG}",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_stream_engine_harness_compiles(tmp_path, lkflow):
+    """tests/cpp/stream_check.cpp (lkflow::StreamEngine over lkflow_stream_*) against the built library: compile / link."""
+    lkflow.lib()
+    exe = _build_stream_check(tmp_path)
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
+def test_stream_engine_device_list_bitwise(tmp_path):
+    """The C-ABI frame-queue engine over the device list {0, 0, 0} (and 1, 4 and 16 entries: more workers than pairs, a
+    1 MiB budget = one pair per call): centroid rows and flows bit-identical to one context walking the stream through the
+    plain C ABI; second push on the same engine; partition rule; argument errors (ParallelVideoPyr.cpp:769-873)."""
+    exe = _build_stream_check(tmp_path)
+    r = subprocess.run([exe, "run", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

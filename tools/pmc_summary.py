@@ -48,10 +48,11 @@ for k in sorted(acc):
                 print(f"   -> {n}/wave = {c[n] / w:10.1f}")
 
 if len(sys.argv) > 2:
-    # bench.py only trusts the file for the workload it was collected on ("<cols>x<rows>x<pairs per launch>")
+    # one JSON per workload ("<cols>x<rows>x<pairs per launch>"), stamped with the digest of the sources the LOADED library was
+    # built from; tools/merge_pmc_traffic.py folds them into profiles/pmc_traffic.json, which bench.py reads per workload
     workload = sys.argv[3] if len(sys.argv) > 3 else "1920x1080x32"
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
+    import __graft_entry__ as ge
     # optional 4th argument: the kernel-trace-by-grid CSV of the same command (tools/kernel_trace_by_grid.py): the mean
     # duration of each kernel's largest-grid (level-0) dispatches is stored next to its traffic
     if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
@@ -62,8 +63,8 @@ if len(sys.argv) > 2:
                 if k not in best or g > best[k][0]:
                     best[k] = (g, float(r["AverageNs"]) / 1e6, int(r["Calls"]))
         for k, (g, ms, n) in best.items():
-            if k in traffic:
-                traffic[k]["rocprof_avg_launch_ms"] = round(ms, 4)
-                traffic[k]["rocprof_dispatches"] = n
+            traffic.setdefault(k, {"grid_work_items": g})
+            traffic[k]["rocprof_avg_launch_ms"] = round(ms, 4)
+            traffic[k]["rocprof_dispatches"] = n
     with open(sys.argv[2], "w") as fh:
-        json.dump({"_workload": workload, "_csrc_sha": bench.csrc_digest(), **traffic}, fh, indent=1)
+        json.dump({"_workload": workload, "_csrc_sha": ge.lib_digest() or "unstamped", **traffic}, fh, indent=1)
