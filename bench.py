@@ -166,13 +166,14 @@ def make_inputs(torch, synth, name, P, rows, cols, dev, seed):
 
 def roofline_objects(lkf, name, cols, rows, levels, win, P, pairs_per_launch, lk0_ms, lk0_n, dt, steps):
     lk0_avg_s = lk0_ms / lk0_n / 1e3
-    kname = lkf.lk_kernel_name(rows, cols, win, has_up=levels > 1, fused_ok=True)
-    lk0_bytes = lk0_bytes_per_pair(cols, rows, levels, "w3x2f" in kname or "w3x1f" in kname) * pairs_per_launch
+    kname = lkf.lk_kernel_name(rows, cols, win, has_up=levels > 1, fused_ok=True, pairs=pairs_per_launch)
+    fused = "w3x2f" in kname or "w3x1f" in kname or kname.endswith(", true, true>")   # the warp of the level runs inside this kernel
+    lk0_bytes = lk0_bytes_per_pair(cols, rows, levels, fused) * pairs_per_launch
     achieved = lk0_bytes / lk0_avg_s
     b_alg = algorithmic_bytes_per_pair(cols, rows, levels, P if name in VIDEO_CONFIGS else 0)
     path_achieved = b_alg * P * steps / dt          # per GPU
     roof = {
-        "kernel": f"{kname} (LK at pyramid level 0" + (", warp fused" if ("w3x2f" in kname or "w3x1f" in kname) else "") +
+        "kernel": f"{kname} (LK at pyramid level 0" + (", warp fused" if fused else "") +
                   (", incl. the trailing workgroups that write the clipped-window frame" if "lk_split" in kname else "") + ")",
         "bound": "hbm",
         "achieved": round(achieved / 1e9, 2),

@@ -58,13 +58,13 @@ const char *lkflow_strerror(int status);
 const char *lkflow_last_error(const lkflow_ctx *ctx);
 /* Library version string. */
 const char *lkflow_version(void);
-/* Diagnostics / measurement: the name (as rocprofv3 prints it) of the LK kernel the library launches for one
- * pyramid level of rows x cols with window `win`; has_up = the level is below the coarsest (it adds the
- * up-sampled coarse flow), fused_ok = the call does not need the level's warped images in memory
- * (i.e. not level 0 of a LKFLOW_MUTATE_INPUTS call).  The answer is for a context with DEFAULT options (LKFLOW_OPT_IMPL,
- * LKFLOW_OPT_FUSE_WARP and LKFLOW_OPT_LK_BATCH select other kernels); the shipped library has no other knob that could
- * change it.  bench.py labels its roofline with it. */
-int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok, char *buf, size_t n);
+/* Diagnostics / measurement: the name (as rocprofv3 prints it) of the LK kernel the library launches for one pyramid level of
+ * rows x cols with window `win` in a batch of n_pairs; has_up = the level is below the coarsest (it adds the up-sampled coarse
+ * flow), fused_ok = the call does not need the level's warped images in memory (i.e. not level 0 of a LKFLOW_MUTATE_INPUTS
+ * call).  The answer is for a context with DEFAULT options on device 0 (LKFLOW_OPT_IMPL, LKFLOW_OPT_FUSE_WARP and
+ * LKFLOW_OPT_LK_BATCH select other kernels); the shipped library has no other knob that could change it.  bench.py labels its
+ * roofline with it. */
+int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok, int n_pairs, char *buf, size_t n);
 
 /* One context per GPU and caller thread: owns the device workspace (pyramids, per-level flow). */
 int lkflow_ctx_create(lkflow_ctx **out, int device);
@@ -83,12 +83,12 @@ int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int 
                                   points move data by asynchronous DMA instead of the pageable path.  ONLY for buffers that
                                   outlive the context or are re-used call after call (a video loop's Mats): a registered
                                   buffer must not be freed while the option is on. */
-#define LKFLOW_OPT_FUSE_WARP 5 /* 0 (default) / 1: windows 5..15 on even levels: the warp of a level runs INSIDE its LK kernel, so
-                                  the warped planes never reach memory -- in the batch-synchronous kernel if LKFLOW_OPT_LK_BATCH is
-                                  on (results within rounding of the default path), else in the wave-specialised kernel with two
-                                  extra "W" waves (bit-identical).  Both measured SLOWER than warp + LK on MI355X (DESIGN.md
-                                  section 4), hence opt-in.  Ignored with LKFLOW_MUTATE_INPUTS at level 0 (the caller wants
-                                  the warped images). */
+#define LKFLOW_OPT_FUSE_WARP 5 /* windows 5..21 on even levels: the warp of a level runs INSIDE its LK kernel (four "W" waves of the
+                                  wave-specialised kernel make the warped rows and hand them over through LDS), so the warped planes
+                                  never reach memory; bit-identical to warp + LK.  0 = never, 1 = wherever the kernel takes the
+                                  shape, 2 (default) = where it was measured faster (levels of >= 256 rows with enough column
+                                  blocks to give every CU a tall strip: DESIGN.md section 4).  Never at level 0 of a
+                                  LKFLOW_MUTATE_INPUTS call (the caller wants the warped images). */
 #define LKFLOW_OPT_LK_BATCH 6  /* 0 (default) / 1: windows 5..15 on even levels run the batch-synchronous LK kernel (lk_batch.h:
                                   8-wave workgroups, 8 rows per barrier pair, 5 window-sum waves next to 3 producer waves)
                                   instead of the wave-specialised one.  Same expressions; the vertical window sums are

@@ -58,6 +58,9 @@
 #ifndef LK_SPLIT_PRIO_F
 #define LK_SPLIT_PRIO_F 3
 #endif
+#ifndef LK_SPLIT_PRIO_W
+#define LK_SPLIT_PRIO_W 2
+#endif
 #ifndef LK_SPLIT_BOTH_MAX
 #define LK_SPLIT_BOTH_MAX 15   /* widest window whose S waves issue the LDS reads of both rows of a step up front */
 #endif
@@ -69,9 +72,6 @@
 #endif
 #ifndef LK_SPLIT_QSUM_ABOVE
 #define LK_SPLIT_QSUM_ABOVE 21   /* windows above this: F publishes the pair sums (SplitCfg::QSUM) */
-#endif
-#ifndef LK_SPLIT_FW_WPE
-#define LK_SPLIT_FW_WPE 3  /* fused warp: 12-wave workgroups, one per CU (three waves per SIMD: <= 168 VGPRs) */
 #endif
 #ifndef LK_SPLIT_TD
 #define LK_SPLIT_TD 2    /* even: row pairs of coarse taps a B lane keeps in flight (4 spills at 15x15 and is slower) */
@@ -104,7 +104,10 @@ struct SplitCfg {
     // gain 4-5 % (3840 x 2160 / L5, level-0 LK 1.00 -> 0.95 ms at 23 x 23, 1.03 -> 0.995 at 27 x 27); the 29 x 29 and
     // 31 x 31 rings would spill (31 x 31: 68 bytes, 8K/L5/w31 level-0 LK 2.02 -> 2.45 ms) and keep one F wave
     // (profiles/r02_j_bigwin_knobs_ab.txt).
-    static constexpr int NF = (!FW && WIN >= LK_SPLIT_NF2_MIN && WIN <= LK_SPLIT_NF2_MAX && WIN > LK_SPLIT_TWO_WG_MAX) ? 2 : 1;
+#ifndef LK_SPLIT_FW_NF
+#define LK_SPLIT_FW_NF 1   /* fused warp: F waves per workgroup (2: each makes the products of ONE row of the step's pair -- 13 waves put four on one SIMD: measured 1.08 -> 1.37 ms, profiles/r04_a_fused_warp_ab.txt) */
+#endif
+    static constexpr int NF = FW ? LK_SPLIT_FW_NF : ((WIN >= LK_SPLIT_NF2_MIN && WIN <= LK_SPLIT_NF2_MAX && WIN > LK_SPLIT_TWO_WG_MAX) ? 2 : 1);
     static constexpr int TXC = 64 * K - 2;           // columns per block with products
     static constexpr int HL = R + (R & 1);           // halo columns on each side (even: a lane's column pair is 16-byte aligned)
     static constexpr int XO = TXC - 2 * HL;          // output columns per block
@@ -120,7 +123,7 @@ struct SplitCfg {
     static constexpr int PROD_D = KH * PSTR * 2;     // doubles per product plane
     static constexpr int SUMS_D = KH * SSTR * 2;     // doubles per sums plane
     // waves per SIMD to compile for (8-wave blocks: 4 -> two blocks per CU; 10-wave blocks with the W role: 5 -> two blocks)
-    static constexpr int WPE = FW ? LK_SPLIT_FW_WPE : ((K == 2 && WIN <= LK_SPLIT_TWO_WG_MAX) ? 4 : (NF == 2 ? 3 : 1));   // nine waves: three on one SIMD
+    static constexpr int WPE = FW ? (NW + 3) / 4 : ((K == 2 && WIN <= LK_SPLIT_TWO_WG_MAX) ? 4 : (NF == 2 ? 3 : 1));   // nine waves: three on one SIMD
     // F publishes the pair sums a + b (true) or S adds the raw pairs itself (false).  Up to 21 x 21 (two workgroups per CU)
     // F is the wave that paces a workgroup and S has slack: S adds (4K/L5/w21 28.4 -> 30.2 Gpx/s).  From 23 x 23 on (one
     // workgroup per CU, 16 LDS reads per row and field) the S waves' LDS reads are the longer pole: halving their bytes
@@ -355,6 +358,10 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     __shared__ __attribute__((aligned(16))) double s_w[FW ? 2 : 1][FW ? 2 : 1][FW ? 2 : 1][FW ? 128 : 2];
     // FW: F's coarse-row service: [step parity][u, v][block column + 2]: the horizontally filtered coarse row W rotates in
     __shared__ __attribute__((aligned(16))) double s_c[FW ? 2 : 1][FW ? 2 : 1][FW ? 128 : 2];
+    // FW: cv::remap's bilinear weight table (OpenCV 2.4 keeps the same table, imgwarp.cpp initInterTab2D): entry (sy & 31) * 32 +
+    // (sx & 31) = the four float weights (1-b)(1-a), (1-b)a, b(1-a), ba as doubles (each an exact multiple of 1/1024) -- two
+    // 16-byte LDS reads per sample instead of 16 vector instructions (and / cvt / mul / sub / 4 mul / 4 cvt)
+    __shared__ __attribute__((aligned(16))) double s_wt[FW ? 1024 : 1][FW ? 4 : 1];
 
     // logical wave (role order B, S, F) of the physical wave: the role -> SIMD placement is an A/B knob (-DLK_SPLIT_PERM=...)
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -387,6 +394,13 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         s_prod[b >> 1][b & 1][f][2 * chunk + 1] = 0.0;
         if constexpr (C::QSUM) s_q[b >> 1][b & 1][f][chunk] = 0.0;
     }
+    if constexpr (FW) {
+        for (int k = threadIdx.x; k < 1024; k += C::NT) {
+            const float fa = (float)(k & 31) * (1.0f / 32), fb = (float)(k >> 5) * (1.0f / 32);   // remap_bilinear's own expressions
+            s_wt[k][0] = (double)((1.0f - fb) * (1.0f - fa)); s_wt[k][1] = (double)((1.0f - fb) * fa);
+            s_wt[k][2] = (double)(fb * (1.0f - fa)); s_wt[k][3] = (double)(fb * fa);
+        }
+    }
     __syncthreads();
 
     // FW: coarse-row bookkeeping shared by the W role and by F's coarse-row service.  A W-step's row pair holds one even
@@ -399,7 +413,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     [[maybe_unused]] auto up_srow_w = [&](int k) { const int Hc = H >> 1; return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };
     [[maybe_unused]] auto rot_row_off = [&](int t) { return max(up_srow_w(((ye0 + 2 * t) >> 1) + 1) - c_lo, 0); };   // row W-step t rotates in
 
-    if (FW && wv > C::NB + 5) {
+    if (FW && wv >= C::NB + 5 + C::NF) {
       if constexpr (FW) {                            // (not even compiled for the unfused kernel)
         // =========================================================================================
         // W waves (fused warp, a9-a12): one column per lane, ONE row of the step's pair per wave -> the warped rows of both
@@ -416,10 +430,10 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // then computes the addresses of step t + 2 while they fly.  Gathers are unconditional, from clamped addresses:
         // taps that fall outside the image are zeroed afterwards (BORDER_CONSTANT 0) in a wave-uniform branch that holds no
         // memory instruction.
-        const int widx = wv - (C::NB + 6);           // 0 .. NWW-1
-#ifdef LK_SPLIT_PRIO_W
+        const int widx = wv - (C::NB + 5 + C::NF);   // 0 .. NWW-1
+        // the W waves issue ahead of the S and B waves (they start the gathers the whole workgroup waits for two steps later;
+        // A/B on 32 x 1080p: level-0 launch 1.087 -> 1.053 ms)
         __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_W);
-#endif
         const int g = (widx & 1) * 64 + ((int)threadIdx.x & 63);   // block column g - 2: the two columns of F lane g >> 1
         const int Hc = H >> 1, Wc = W >> 1;
         const int xcol = min(max(x0 + 2 * ((g >> 1) - 1), 0), W - 2) + (g & 1);   // F's clamped column pair
@@ -431,7 +445,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         auto wrole = [&](auto ec) __attribute__((always_inline)) {
         constexpr int E = decltype(ec)::value;       // this wave's row of every step's pair
         double hu[3], hv[3];
-        struct WAddr { int vo[2], sx[2], sy[2]; };   // per image
+        struct WAddr { int vo[2], wi[2], dx[2], dy[2]; };  // per image: gather byte offset, weight-table byte offset, distance of the real tap block from the clamped one (0, 0: all taps inside)
         // rotation of W-step t with the new coarse row (nu, nv), up-sampled flow of this wave's row, map, fixed-point coordinates
         auto waddr = [&](int t, double nu, double nv, WAddr &A) __attribute__((always_inline)) {
             const int ye = ye0 + 2 * t;
@@ -455,13 +469,23 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             // others feed products that F zeroes, any in-image row will do
             const float yf = (float)min(yy < 0 ? -yy : yy, H - 1);
             const float hx = (float)uu / 2, hy = (float)vv / 2;   // map build (ParallelVideoPyr.cpp:674-678), float32
+#ifdef LK_ABL_W_NOADDR   /* timing-only ablation: results wrong */
+            A.vo[0] = A.vo[1] = (int)(hx + hy + yf) & 0xFF8; A.wi[0] = A.wi[1] = 0; A.oob[0] = A.oob[1] = 0;
+            if (0)
+#endif
 #pragma unroll
             for (int im = 0; im < 2; ++im) {
                 const float mx = im ? xf - hx : xf + hx, my = im ? yf - hy : yf + hy;
                 const int sx = cv_round_f(mx * 32.0f), sy = cv_round_f(my * 32.0f);
-                const int ixc = min(max(sat_short(sx >> 5), 0), W - 2), iyc = min(max(sat_short(sy >> 5), 0), H - 2);
-                A.vo[im] = iyc * ipb + ixc * 8;
-                A.sx[im] = sx; A.sy[im] = sy;
+                // (host-checked for this kernel: W, H <= 32766, so cv::remap's saturation of the tap coordinates to short cannot move
+                // a coordinate into or inside the image: clamping the unsaturated value gives the same address, and its distance
+                // from the clamp classifies the taps -- 0, +-1, or anything else = all outside -- like the saturated one)
+                const int ix = sx >> 5, iy = sy >> 5;
+                const int ixc = min(max(ix, 0), W - 2), iyc = min(max(iy, 0), H - 2);
+                // (host-checked for this kernel: the plane has fewer than 2^24 bytes per row and fewer than 2^24 rows -- 24-bit multiply)
+                A.vo[im] = (int)__umul24((unsigned)iyc, (unsigned)ipb) + ixc * 8;
+                A.wi[im] = ((sy & 31) << 10) | ((sx & 31) << 5);          // byte offset of the 32-byte table entry
+                A.dx[im] = ix - ixc; A.dy[im] = iy - iyc;
             }
         };
         lk_d2 G[2][2];                               // gathers in flight: [image][tap row] = columns (ixc, ixc + 1)
@@ -470,8 +494,12 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             for (int im = 0; im < 2; ++im) {
                 const __amdgpu_buffer_rsrc_t rI = im ? rI2 : rI1;
                 double g0x, g0y, g1x, g1y;
+#ifdef LK_ABL_W_NOLOAD   /* timing-only ablation: results wrong */
+                g0x = g0y = g1x = g1y = (double)A.vo[im]; (void)rI;
+#else
                 buf_ld2(rI, A.vo[im], 0, g0x, g0y);
                 buf_ld2(rI, A.vo[im], ipb, g1x, g1y);
+#endif
                 G[im][0].x = g0x; G[im][0].y = g0y; G[im][1].x = g1x; G[im][1].y = g1y;
             }
         };
@@ -479,13 +507,11 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             constexpr int WP = decltype(pc)::value;
 #pragma unroll
             for (int im = 0; im < 2; ++im) {
-                const int sx = A.sx[im], sy = A.sy[im];
-                const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
-                const int dx = ix - min(max(ix, 0), W - 2), dy = iy - min(max(iy, 0), H - 2);
-                const float fa = (float)(sx & 31) * (1.0f / 32), fb = (float)(sy & 31) * (1.0f / 32);
-                const float w0 = (1.0f - fb) * (1.0f - fa), w1 = (1.0f - fb) * fa, w2 = fb * (1.0f - fa), w3 = fb * fa;
+                const char *wt = reinterpret_cast<const char *>(&s_wt[0][0]) + A.wi[im];
+                const lk_d2 w01 = *reinterpret_cast<const lk_d2 *>(wt), w23 = *reinterpret_cast<const lk_d2 *>(wt + 16);
                 lk_d2 top = G[im][0], bot = G[im][1];
-                if (__builtin_amdgcn_ballot_w64((dx | dy) != 0) != 0) {   // some lane's taps leave the image (wave-uniform, no memory instruction)
+                if (__builtin_amdgcn_ballot_w64((A.dx[im] | A.dy[im]) != 0) != 0) {   // some lane's taps leave the image (wave-uniform, no memory instruction)
+                    const int dx = A.dx[im], dy = A.dy[im];
                     const lk_d2 z = {0.0, 0.0};
                     const lk_d2 t0 = top, t1 = bot;
                     top = dy == 0 ? t0 : (dy == 1 ? t1 : z);
@@ -494,7 +520,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
                     top.x = dx == 0 ? a0.x : (dx == 1 ? a0.y : 0.0); top.y = dx == 0 ? a0.y : (dx == -1 ? a0.x : 0.0);
                     bot.x = dx == 0 ? a1.x : (dx == 1 ? a1.y : 0.0); bot.y = dx == 0 ? a1.y : (dx == -1 ? a1.x : 0.0);
                 }
-                s_w[WP][E][im][g] = top.x * (double)w0 + top.y * (double)w1 + bot.x * (double)w2 + bot.y * (double)w3;
+                s_w[WP][E][im][g] = top.x * w01.x + top.y * w01.y + bot.x * w23.x + bot.y * w23.y;
             }
         };
         WAddr cur, nxt;
@@ -515,18 +541,18 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             srow(rot_row_off(1), nu, nv); waddr(1, nu, nv, nxt);
         }
         __syncthreads();                             // F's service has published the row W-step 2 rotates in
-        auto wstep = [&](auto pc, int t) __attribute__((always_inline)) {
+        // (the two address records swap roles from step to step: no copies)
+        auto wstep = [&](auto pc, int t, WAddr &now, WAddr &next) __attribute__((always_inline)) {
             constexpr int WP = decltype(pc)::value;
-            wblend(pc, cur);
-            wissue(nxt);
-            cur = nxt;
+            wblend(pc, now);
+            wissue(next);
             const double nu = s_c[WP ^ 1][0][g], nv = s_c[WP ^ 1][1][g];   // written by F in step t - 1: the row step t + 2 rotates in
-            waddr(t + 2, nu, nv, nxt);
+            waddr(t + 2, nu, nv, now);
             __syncthreads();
         };
         for (int t = 0; t < NS; t += 2) {                               // NS is even
-            wstep(std::integral_constant<int, 0>{}, t);
-            wstep(std::integral_constant<int, 1>{}, t + 1);
+            wstep(std::integral_constant<int, 0>{}, t, cur, nxt);
+            wstep(std::integral_constant<int, 1>{}, t + 1, nxt, cur);
         }
         };
         if (widx < 2) wrole(std::integral_constant<int, 0>{});          // (wave-uniform)
@@ -559,18 +585,24 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         const __amdgpu_buffer_rsrc_t rCU = buf_rsrc(a.cu.at(pair) + (long long)c_lo * a.cu.pitch, ((long long)(Hc - 1 - c_lo) * a.cu.pitch + Wc) * 8);
         const __amdgpu_buffer_rsrc_t rCV = buf_rsrc(a.cv.at(pair) + (long long)c_lo * a.cv.pitch, ((long long)(Hc - 1 - c_lo) * a.cv.pitch + Wc) * 8);
         double tpf[6];
+        // (two F waves: wave 0 serves the u plane, wave 1 the v plane)
         auto svc_load = [&](int t) __attribute__((always_inline)) {     // taps of the row W-step t rotates in
             const int sr = rot_row_off(t), su = sr * cpub, sv = sr * cpvb;
-            tpf[0] = buf_ld(rCU, usA.jm, su); tpf[1] = buf_ld(rCU, usA.jc, su); tpf[2] = buf_ld(rCU, usA.jp, su);
-            tpf[3] = buf_ld(rCV, usA.jm, sv); tpf[4] = buf_ld(rCV, usA.jc, sv); tpf[5] = buf_ld(rCV, usA.jp, sv);
+            if (C::NF == 1 || fe == 0) { tpf[0] = buf_ld(rCU, usA.jm, su); tpf[1] = buf_ld(rCU, usA.jc, su); tpf[2] = buf_ld(rCU, usA.jp, su); }
+            if (C::NF == 1 || fe == 1) { tpf[3] = buf_ld(rCV, usA.jm, sv); tpf[4] = buf_ld(rCV, usA.jc, sv); tpf[5] = buf_ld(rCV, usA.jp, sv); }
         };
         auto svc_publish = [&](auto pc) __attribute__((always_inline)) {
             constexpr int P = decltype(pc)::value;
-            lk_d2 ou, ov;
-            ou.x = pyrup_h1v(tpf[0], tpf[1], tpf[2], usA); ou.y = pyrup_h1v(tpf[0], tpf[1], tpf[2], usB);
-            ov.x = pyrup_h1v(tpf[3], tpf[4], tpf[5], usA); ov.y = pyrup_h1v(tpf[3], tpf[4], tpf[5], usB);
-            *reinterpret_cast<lk_d2 *>(&s_c[P][0][2 * m]) = ou;
-            *reinterpret_cast<lk_d2 *>(&s_c[P][1][2 * m]) = ov;
+            if (C::NF == 1 || fe == 0) {
+                lk_d2 ou;
+                ou.x = pyrup_h1v(tpf[0], tpf[1], tpf[2], usA); ou.y = pyrup_h1v(tpf[0], tpf[1], tpf[2], usB);
+                *reinterpret_cast<lk_d2 *>(&s_c[P][0][2 * m]) = ou;
+            }
+            if (C::NF == 1 || fe == 1) {
+                lk_d2 ov;
+                ov.x = pyrup_h1v(tpf[3], tpf[4], tpf[5], usA); ov.y = pyrup_h1v(tpf[3], tpf[4], tpf[5], usB);
+                *reinterpret_cast<lk_d2 *>(&s_c[P][1][2 * m]) = ov;
+            }
         };
         svc_load(2); svc_publish(std::integral_constant<int, 1>{}); svc_load(3);
         __syncthreads();
@@ -590,12 +622,18 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
                     for (int im = 0; im < 2; ++im) { ca[im] = rw[E][im].x; cb[im] = rw[E][im].y; cl[im] = left_tap(cb[im]); }
                     const int yy = yy0 + 2 * (t - 2) + E;
                     const bool row_in = yy >= 0 && yy < H;
+                    if (C::NF == 1 || fe == E) {                // (wave-uniform: two F waves make one row of the pair each)
+#ifdef LK_ABL_F   /* timing-only ablation: results wrong */
+                    double fxa = pl[0] + ca[0], fya = pa[0] + cl[1], fxb = pb[0], fyb = cb[1];
+                    const double fta = ca[1], ftb = cb[0];
+#else
                     double fxa = f2d_x(pl[0], pa[0], cl[0], ca[0]) + f2d_x(pl[1], pa[1], cl[1], ca[1]);
                     double fya = f2d_y(pl[0], pa[0], cl[0], ca[0]) + f2d_y(pl[1], pa[1], cl[1], ca[1]);
                     const double fta = f2d_neg(pl[0], pa[0], cl[0], ca[0]) + f2d_pos(pl[1], pa[1], cl[1], ca[1]);
                     double fxb = f2d_x(pa[0], pb[0], ca[0], cb[0]) + f2d_x(pa[1], pb[1], ca[1], cb[1]);
                     double fyb = f2d_y(pa[0], pb[0], ca[0], cb[0]) + f2d_y(pa[1], pb[1], ca[1], cb[1]);
                     const double ftb = f2d_neg(pa[0], pb[0], ca[0], cb[0]) + f2d_pos(pa[1], pb[1], ca[1], cb[1]);
+#endif
                     if (!(row_in && all_col_in)) {              // rows / columns outside the image contribute 0 (wave-uniform test)
                         const bool keep = row_in && col_in;
                         fxa = keep ? fxa : 0.0; fya = keep ? fya : 0.0;
@@ -610,6 +648,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
                     put(std::integral_constant<int, 2>{}, fxa * fya, fxb * fyb);
                     put(std::integral_constant<int, 3>{}, fxa * fta, fxb * ftb);
                     put(std::integral_constant<int, 4>{}, fya * fta, fyb * ftb);
+                    }
 #pragma unroll
                     for (int im = 0; im < 2; ++im) { pl[im] = cl[im]; pa[im] = ca[im]; pb[im] = cb[im]; }
                 }(), ...);
@@ -798,7 +837,11 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             const double un = S[2] * S[4] - S[1] * S[3];
             const double vn = S[3] * S[2] - S[0] * S[4];
             const bool nz = det != 0.0;                     // cv::divide: x/0 -> 0
+#ifdef LK_ABL_B   /* timing-only ablation: results wrong */
+            const double qu = un + det, qv = vn + det;
+#else
             const double qu = un / det, qv = vn / det;
+#endif
             u = nz ? qu : 0.0;
             v = nz ? qv : 0.0;
         };

@@ -66,7 +66,7 @@ struct Level {
 }  // namespace
 
 #ifndef LKFLOW_SPLIT_FUSED_DEFAULT
-#define LKFLOW_SPLIT_FUSED_DEFAULT 0                 /* A/B builds: -DLKFLOW_SPLIT_FUSED_DEFAULT=1 */
+#define LKFLOW_SPLIT_FUSED_DEFAULT 2                 /* LKFLOW_OPT_FUSE_WARP: 0 never, 1 wherever the kernel takes the shape, 2 where it is faster */
 #endif
 struct lkflow_ctx {
     int device = 0;
@@ -398,7 +398,8 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s, i
     using C = lk::SplitCfg<WIN, K, true>;
     if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return LK_NOT_TAKEN;
     // the W role addresses a whole image plane with 32-bit byte offsets and one pitch for both images
-    if (a.i1.pitch != a.i2.pitch || (long long)a.H * a.i1.pitch * 8 > 0x7fffffffLL) return LK_NOT_TAKEN;
+    // (forms row * pitch with a 24-bit multiply and clamps unsaturated tap coordinates: see the W role)
+    if (a.i1.pitch != a.i2.pitch || (long long)a.H * a.i1.pitch * 8 > 0x7fffffffLL || a.i1.pitch * 8 >= (1 << 24) || a.H > 32766 || a.W > 32766) return LK_NOT_TAKEN;
     const int gx = (a.W + C::XO - 1) / C::XO;
     int th = ctx->tile_rows;
     if (th <= 0) {
@@ -432,17 +433,17 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s, i
     return LKFLOW_OK;
 }
 
-#define LKFLOW_SPLIT_FUSED_MAX_WIN 15                // bigger rings do not fit the 96 VGPRs of a 10-wave block pair
-bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H);
+#define LKFLOW_SPLIT_FUSED_MAX_WIN 21                // 12-wave workgroups, one per CU: <= 168 VGPRs (bigger rings: not built)
+bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H, int pairs);
 
 int launch_splitw(lkflow_ctx *ctx, const lk::LKArgs &a, int pairs, int win, hipStream_t s, int level)
 {
     switch (win) {
 #define SP_CASE(WN) case WN: return launch_splitw_win<WN, 2>(ctx, a, pairs, s, level);
 #ifdef LKFLOW_FAST_BUILD
-        SP_CASE(15)
+        SP_CASE(15) SP_CASE(21)
 #else
-        SP_CASE(5) SP_CASE(7) SP_CASE(9) SP_CASE(11) SP_CASE(13) SP_CASE(15)
+        SP_CASE(5) SP_CASE(7) SP_CASE(9) SP_CASE(11) SP_CASE(13) SP_CASE(15) SP_CASE(17) SP_CASE(19) SP_CASE(21)
 #endif
 #undef SP_CASE
         default: return LK_NOT_TAKEN;
@@ -457,10 +458,21 @@ bool split_applies(int win, int W, int H)
     return split && win >= 5 && win <= LKFLOW_MAX_WIN && !(W & 1) && !(H & 1) && W >= 2 && H > R + LK_SPLIT_PF + 1;
 }
 
-bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H)
+// Windows 5..21 on even levels: run the warp of the level inside the wave-specialised LK kernel (lk_split.h, W role: the warped
+// planes never reach memory)?  LKFLOW_OPT_FUSE_WARP 1: wherever the kernel takes the shape; 2 (default): where it was measured
+// faster than warp + LK -- levels of at least 256 rows (a 12-wave workgroup has a CU to itself and marches a tall strip: its
+// pipeline fill and its weight table are paid per strip) with at least half a column block per CU (32 x 1080p: level 0
+// 1.09 -> 1.01 ms, level 1 0.319 -> 0.312; 8 x 3840x2160 / w21: 1.14 -> 1.07; the 245-frame 240 x 160 stream: 0.23 -> 0.27,
+// hence not there: profiles/r04_a_fused_warp_ab.txt).
+bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H, int pairs)
 {
     static const int env = knob("LKFLOW_SPLIT_FUSED", -1);       // A/B: overrides the option
-    return (env >= 0 ? env : ctx->fuse_warp) && ctx->impl == 0 && win <= LKFLOW_SPLIT_FUSED_MAX_WIN && split_applies(win, W, H);
+    const int mode = env >= 0 ? env : ctx->fuse_warp;
+    if (!mode || ctx->impl != 0 || win > LKFLOW_SPLIT_FUSED_MAX_WIN || !split_applies(win, W, H)) return false;
+    if (mode == 1) return true;
+    using C15 = lk::SplitCfg<15, 2, true>;                       // (XO depends on the window; this is only a size rule)
+    const long long col_blocks = (long long)((W + C15::XO - 1) / C15::XO) * pairs;
+    return H >= 256 && 2 * col_blocks >= ctx->n_cu;
 }
 
 // LK_NOT_TAKEN: this window has no wave-specialised instantiation
@@ -732,9 +744,9 @@ const char *lkflow_strerror(int status)
 const char *lkflow_last_error(const lkflow_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 const char *lkflow_version(void) { return LKFLOW_VERSION_STR; }
 
-int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok, char *buf, size_t n)
+int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok, int n_pairs, char *buf, size_t n)
 {
-    if (!buf || n == 0 || rows < 1 || cols < 1) return LKFLOW_E_ARG;
+    if (!buf || n == 0 || rows < 1 || cols < 1 || n_pairs < 1) return LKFLOW_E_ARG;
     int rc = check_win(win);
     if (rc) return rc;
     const char *up = has_up ? "true" : "false";
@@ -744,7 +756,14 @@ int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok,
         snprintf(buf, n, "%s", knob("LKFLOW_W3_ONE_COLUMN", LKFLOW_W3_ONE_COLUMN) ? "lk::lk_w3x1f_kernel" : "lk::lk_w3x2f_kernel");
     else if (win == 3 && !no_x2 && cols >= 2 && !(cols & 1)) snprintf(buf, n, "lk::lk_w3x2_kernel<%s>", up);
     else if (win == 3) snprintf(buf, n, "lk::lk_march3_kernel<3, 64, %s>", up);
-    else if (split_applies(win, cols, rows)) snprintf(buf, n, "lk::lk_split_kernel<%d, 2, %s, false>", win, up);   // (..., true> with LKFLOW_OPT_FUSE_WARP)
+    else if (split_applies(win, cols, rows)) {
+        lkflow_ctx dflt;                                         // default options; the CU count of device 0 if there is one
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess && ncu > 0) dflt.n_cu = ncu;
+        else (void)hipGetLastError();
+        const bool fused = has_up && fused_ok && fused_split_applies(&dflt, win, cols, rows, n_pairs);
+        snprintf(buf, n, "lk::lk_split_kernel<%d, 2, %s, %s>", win, up, fused ? "true" : "false");
+    }
     else {
         snprintf(buf, n, "lk::lk_march3_kernel<%d, %d, %s>", win, lk3_block_width(win), up);
     }
@@ -799,7 +818,7 @@ int lkflow_ctx_set_option(lkflow_ctx *ctx, int key, int value)
             ctx->impl = value;
             return LKFLOW_OK;
         case LKFLOW_OPT_FUSE_WARP:
-            if (value < 0 || value > 1) return LKFLOW_E_ARG;
+            if (value < 0 || value > 2) return LKFLOW_E_ARG;
             ctx->fuse_warp = value;
             return LKFLOW_OK;
         case LKFLOW_OPT_LK_BATCH:
@@ -1004,7 +1023,7 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
             if ((rc = launch_w3x2f(ctx, a, P, s))) return rc;
             continue;
         }
-        if (has_up && ctx->fuse_warp && batch_applies(ctx, win, lv[l].W, lv[l].H) && !((flags & LKFLOW_MUTATE_INPUTS) && l == 0)) {
+        if (has_up && ctx->fuse_warp == 1 && batch_applies(ctx, win, lv[l].W, lv[l].H) && !((flags & LKFLOW_MUTATE_INPUTS) && l == 0)) {
             // windows 5..15: warp and LK in one batch-synchronous kernel (lk_batch.h), the warped images never reach memory
             lk::LKArgs f = a;
             f.i1 = pyr(l, 0); f.i2 = pyr(l, 1);
@@ -1013,7 +1032,7 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
             if (rc == LKFLOW_OK) { HIP_TRY(ctx, hipGetLastError()); continue; }
             if (rc != LK_NOT_TAKEN) return rc;                   // not taken: warp + LK below
         } else
-        if (has_up && fused_split_applies(ctx, win, lv[l].W, lv[l].H) && !((flags & LKFLOW_MUTATE_INPUTS) && l == 0)) {
+        if (has_up && fused_split_applies(ctx, win, lv[l].W, lv[l].H, P) && !((flags & LKFLOW_MUTATE_INPUTS) && l == 0)) {
             // windows 5..15: warp and LK in one kernel (lk_split.h, W role), the warped images never reach memory
             lk::LKArgs f = a;
             f.i1 = pyr(l, 0); f.i2 = pyr(l, 1);

@@ -132,10 +132,10 @@ def lib():
     return _LIB
 
 
-def lk_kernel_name(rows, cols, win, has_up=True, fused_ok=True):
-    """Name (as rocprofv3 prints it) of the LK kernel the library launches for one pyramid level."""
+def lk_kernel_name(rows, cols, win, has_up=True, fused_ok=True, pairs=1):
+    """Name (as rocprofv3 prints it) of the LK kernel the library launches for one pyramid level of a batch of `pairs`."""
     buf = ctypes.create_string_buffer(128)
-    rc = lib().lkflow_lk_kernel_name(int(rows), int(cols), int(win), int(has_up), int(fused_ok), buf, 128)
+    rc = lib().lkflow_lk_kernel_name(int(rows), int(cols), int(win), int(has_up), int(fused_ok), int(pairs), buf, 128)
     if rc != 0:
         raise LKFlowError(rc)
     return buf.value.decode()

@@ -48,7 +48,7 @@ def test_committed_pmc_traffic_is_usable_by_bench():
     if rec.get("_csrc_sha") == bench.csrc_digest() == bench.loaded_lib_digest():
         sys.path.insert(0, os.path.join(ROOT, "optical-flow_amd"))
         import lkflow_amd                                    # the name bench.py looks up is the one rocprofv3 printed
-        assert lkflow_amd.lk_kernel_name(rows, cols, win, has_up=True) in names
+        assert lkflow_amd.lk_kernel_name(rows, cols, win, has_up=True, pairs=pairs) in names
         alg = bench.lk0_bytes_per_pair(cols, rows, levels) * pairs
         assert any(t is not None and alg <= t <= 2 * alg for t in ts)
         assert any(bench.rocprof_avg_launch_ms(k, cols, rows, pairs) for k in names)

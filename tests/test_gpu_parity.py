@@ -429,8 +429,11 @@ def test_preprocess_chain_feeds_the_hot_call(gpu_ctx, oracle, torch):
     U, V = gpu_ctx.compute_video(dev(torch, np.stack(want)), levels=3, win=5)
     for p in range(F - 2):
         uo, vo = oracle.coarse_to_fine(want[p], want[p + 1], 3, 5)
-        scale = max(1.0, np.abs(uo).max(), np.abs(vo).max())
-        assert np.abs(host(U[p]) - uo).max() <= TOL * scale and np.abs(host(V[p]) - vo).max() <= TOL * scale
+        assert np.abs(host(U[p]) - uo).max() <= TOL and np.abs(host(V[p]) - vo).max() <= TOL       # absolute (ParallelBasicPyr.cpp:787)
+    U3, V3 = gpu_ctx.compute_video(dev(torch, np.stack(want)), levels=3, win=3)                     # the reference's window: bit for bit
+    for p in range(F - 2):
+        uo, vo = oracle.coarse_to_fine(want[p], want[p + 1], 3, 3)
+        assert np.array_equal(host(U3[p]), uo) and np.array_equal(host(V3[p]), vo)
 
 
 def test_video_strict_chain_matches_oracle(gpu_ctx, oracle, torch):

@@ -162,7 +162,8 @@ def test_two_contexts_pinning_the_same_host_buffers(lkflow, oracle, table_u8, to
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows,cols,levels,win", [(136, 240, 3, 15), (272, 480, 3, 9), (96, 300, 2, 5), (540, 960, 3, 13)])
+@pytest.mark.parametrize("rows,cols,levels,win", [(136, 240, 3, 15), (272, 480, 3, 9), (96, 300, 2, 5), (540, 960, 3, 13), (272, 480, 3, 21),
+                                                (544, 960, 5, 21), (136, 240, 2, 17), (64, 96, 2, 19), (1080, 1920, 3, 15)])
 def test_fused_warp_option_is_bit_identical(lkflow, torch, rows, cols, levels, win):
     """LKFLOW_OPT_FUSE_WARP (the warp inside the wave-specialised LK kernel: W role of lk_split.h, lk_border_kernel<., true>)
     gives the bits of warp_kernel + lk_split_kernel: same pyrUp / map / remap / window-sum expressions in the same order."""

@@ -61,7 +61,7 @@ def test_fuzz_slice_all_windows(gpu_ctx, lkflow, oracle, torch):
     """60 seeded cases of tools/fuzz_small.py (random rows / cols / levels / window out of all 15 / batch size, flat
     half-images, video batches) against the oracle -- the builder-side fuzz runs 400."""
     rng = np.random.default_rng(31)
-    worst = 0.0
+    worst, n_big, n_px = 0.0, 0, 0
     for it in range(60):
         lv_target = int(rng.integers(1, 6))
         h = int(rng.integers(1, 48)) << (lv_target - 1)
@@ -82,11 +82,19 @@ def test_fuzz_slice_all_windows(gpu_ctx, lkflow, oracle, torch):
         U, V = host(U), host(V)
         for p in range(P):
             uo, vo = oracle.coarse_to_fine(pa[p], pb[p], levels, win)
-            scale = np.maximum(1.0, np.maximum(np.abs(uo), np.abs(vo)))
-            e = max((np.abs(U[p] - uo) / scale).max(), (np.abs(V[p] - vo) / scale).max())
+            # the reference's bar is ABSOLUTE (ParallelBasicPyr.cpp:787).  White noise under a big window gives flows of 1e3 and
+            # more at ill-conditioned pixels, whose last bits alone exceed 1e-6: those pixels -- counted and printed -- are held
+            # to the same bar relative to their magnitude, every other pixel to the absolute one
+            mag = np.maximum(np.abs(uo), np.abs(vo))
+            e_abs = np.maximum(np.abs(U[p] - uo), np.abs(V[p] - vo))
+            big = e_abs > TOL
+            n_big += int(big.sum()); n_px += big.size
+            assert (mag[big] > 1e2).all(), (it, h, w, levels, win, P, float(e_abs.max()))
+            e = float((e_abs / np.maximum(1.0, mag)).max())
             worst = max(worst, e)
             assert e <= TOL, (it, h, w, levels, win, P, e)
-    print(f"fuzz slice: worst relative error {worst:.3e}")
+    print(f"fuzz slice: {n_big} of {n_px} pixels beyond the absolute 1e-6 (all with |flow| > 100, held relatively); ", end="")
+    print(f"worst relative error {worst:.3e}")
 
 
 # ---------------------------------------------------------------------------- the bench's own launch geometries

@@ -144,13 +144,12 @@ def test_edge_map_stream_strict_chain(gpu_ctx, oracle, edge_stream, torch):
 
 @pytest.mark.parametrize("levels,win", [(3, 15), (5, 21), (4, 5)])
 def test_edge_map_crop_big_windows_absolute_bar(gpu_ctx, lkflow, oracle, edge_stream, torch, levels, win):
-    """The same edge maps at the BASELINE windows (w15 / L3, w21 / L5; w5 / L4) on a 272 x 480 crop around the moving hand.
-    Windows other than 3 x 3 have no reference (generalised `win`), and the kernels add a window's
-    win^2 terms in a separable order, the oracle row-major: where a window holds nothing but rounding residue (straight
-    edges: det is the difference of two equal products) the quotient of two residues is a different arbitrary number in
-    each order.  So: every pixel whose determinant is not pure residue must meet the ABSOLUTE 1e-6; the others are
-    counted, printed, and must be residue pixels by the oracle's own evidence (|det| below 1e-9 of Sxx * Syy at some
-    level of the pyramid, or fed by such a pixel through the warp)."""
+    """The same edge maps at the BASELINE windows (w15 / L3, w21 / L5; w5 / L4) on a 272 x 480 crop around the moving hand,
+    at the reference's ABSOLUTE 1e-6.  Windows other than 3 x 3 have no reference (generalised `win`) and
+    the marching kernels add a window's win^2 terms in a separable order, the oracle row-major; on integer-valued edge maps
+    most sums are exact in either order, so the two agree far below the bar (measured: <= 2e-8 on this stream).  The
+    per-pixel kernel (LKFLOW_OPT_IMPL = 1), which adds in the oracle's order, is run beside it: it must equal the oracle to
+    the bit, which pins everything around the window sum (pyramid, warp, solve) on this input class."""
     y0, x0 = 200, 180
     crop = edge_stream[:3, y0:y0 + 272, x0:x0 + 480].contiguous()
     U, V = gpu_ctx.compute_video(crop, levels, win)
@@ -168,8 +167,6 @@ def test_edge_map_crop_big_windows_absolute_bar(gpu_ctx, lkflow, oracle, edge_st
         worst_good = max(worst_good, float(e[~bad].max()))
         print(f"edge crop L{levels} w{win} pair {p}: {int(bad.sum())} of {bad.size} pixels beyond 1e-6 "
               f"(max {float(e.max()):.3e}); reference-order kernel: {int((en > TOL).sum())} beyond 1e-6 (max {float(en.max()):.3e})")
-        # the per-pixel kernel adds in the oracle's order: it must meet the absolute bar everywhere -- which shows that what
-        # the marching kernels differ by at the counted pixels is the summation order of residue windows, not a defect
-        assert float(en.max()) <= TOL
-        assert bad.mean() <= 0.02, (p, float(bad.mean()))
-    print(f"edge crop L{levels} w{win}: {nbad_total} residue pixels in all; every other pixel within {worst_good:.3e}")
+        assert float(en.max()) == 0.0                                  # same order as the oracle: same bits
+        assert int(bad.sum()) == 0, (p, int(bad.sum()), float(e.max()))
+    print(f"edge crop L{levels} w{win}: every pixel within {worst_good:.3e} of the oracle")
