@@ -189,6 +189,10 @@ def roofline_objects(lkf, name, cols, rows, levels, win, P, pairs_per_launch, lk
         "launches_timed": lk0_n,
         "pairs_per_launch": pairs_per_launch,
     }
+    # the same fraction from the COMMITTED rocprofv3 kernel trace (profiles/*_kernel_trace_by_grid.csv via pmc_traffic.json): the
+    # figure a reader can re-derive from profiles/ alone; null until tools/prof_round.sh has been re-run on this code
+    rp = roof["rocprof_avg_launch_ms"]
+    roof["frac_rocprof"] = round(lk0_bytes / (rp * 1e-3) / HBM_PEAK, 4) if rp else None
     path = {
         "algorithmic_bytes_per_pair": b_alg,
         "achieved_GBps_per_gpu": round(path_achieved / 1e9, 2),

@@ -190,6 +190,15 @@ int lkflow_pyrdown_f64_dev(lkflow_ctx *ctx, const double *src, size_t src_plane_
                            int n_planes, int rows, int cols, size_t src_step_bytes, double *dst,
                            size_t dst_plane_stride_bytes, size_t dst_step_bytes, void *stream);
 
+/* Two levels of getGaussianPyramid (ParallelVideoPyr.cpp:566-575) in one pass: dst1 = pyrDown(src) (rows/2 x cols/2), dst2 =
+ * pyrDown(dst1) (rows/4 x cols/4), bit-identical to two lkflow_pyrdown_f64_dev calls; the source is read once and dst1 is not
+ * read back.  rows and cols multiples of 4, cols >= 16, rows >= 8 (other shapes: LKFLOW_E_ARG -- the pyramid driver then runs
+ * two single-level passes). */
+int lkflow_pyrdown2_f64_dev(lkflow_ctx *ctx, const double *src, size_t src_plane_stride_bytes, int n_planes, int rows,
+                            int cols, size_t src_step_bytes, double *dst1, size_t dst1_plane_stride_bytes,
+                            size_t dst1_step_bytes, double *dst2, size_t dst2_plane_stride_bytes, size_t dst2_step_bytes,
+                            void *stream);
+
 /* cv::pyrUp (ParallelVideoPyr.cpp:646-647): dst is (2*rows) x (2*cols). */
 int lkflow_pyrup_f64_dev(lkflow_ctx *ctx, const double *src, size_t src_plane_stride_bytes,
                          int n_planes, int rows, int cols, size_t src_step_bytes, double *dst,
@@ -205,6 +214,12 @@ int lkflow_warp_f64_dev(lkflow_ctx *ctx, const double *img1, const double *img2,
                         size_t img_step_bytes, const double *cu, const double *cv,
                         size_t c_plane_stride_bytes, size_t c_step_bytes, double *out1, double *out2,
                         size_t out_plane_stride_bytes, size_t out_step_bytes, void *stream);
+
+/* The 2 x 2 solve + cv::divide (x / 0 -> 0) of one LK level (ParallelVideoPyr.cpp:470-472, 510-520) on n pixels: S holds
+ * five contiguous planes of n window sums (Sxx, Syy, Sxy, Sxt, Syt).  plain_divisions = 0: as every LK kernel computes it (both
+ * quotients share one reciprocal iteration, each correctly rounded), 1: two independent IEEE divisions -- the cross-check. */
+int lkflow_solve_f64_dev(lkflow_ctx *ctx, const double *S, size_t n, double *u, double *v, int plain_divisions,
+                         void *stream);
 
 /* convertTo(CV_64FC1, 1.0/255) (SerialPyr.cpp:237) for n contiguous bytes. */
 int lkflow_u8_to_f64_dev(lkflow_ctx *ctx, const unsigned char *src, double *dst, size_t n,

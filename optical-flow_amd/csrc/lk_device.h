@@ -78,9 +78,51 @@ __device__ __forceinline__ void lk_products_at(const double *I1, const double *I
     lk_products(r0a[xm], r0a[x], r1a[xm], r1a[x], r0b[xm], r0b[x], r1b[xm], r1b[x], p);
 }
 
+// x1 / y and x2 / y, both correctly rounded (IEEE-754 binary64, every input class), sharing the reciprocal iteration.
+// hipcc expands an fp64 division into  d = div_scale(den) ; r = rcp(d) + two Newton steps (4 FMA) ; n = div_scale(num) ;
+// q = n r ; rem = fma(-d, q, n) ; div_fmas ; div_fixup  -- eleven instructions, of which the first six depend on the numerator
+// only through div_scale's choice of a scale for extreme exponent differences.  The two divisions of the LK solve have one
+// denominator (det): when the scaled denominators of both come out bit-equal in every lane of the wave (always, outside
+// exponent differences of several hundred binades) the reciprocal is refined once and each quotient takes its own five
+// closing instructions -- the same instructions on the same inputs as the two full expansions, hence the same bits; otherwise
+// (wave-uniform branch) the two full divisions run.  17 instructions and one v_rcp_f64 per pixel instead of 22 and two.
+__device__ __forceinline__ void lk_div2(double x1, double x2, double y, double &q1, double &q2)
+{
+    bool f1, f2, fd;
+    const double d1 = __builtin_amdgcn_div_scale(x1, y, false, &fd);
+    const double d2 = __builtin_amdgcn_div_scale(x2, y, false, &fd);
+    if (__builtin_amdgcn_ballot_w64(__double_as_longlong(d1) != __double_as_longlong(d2)) == 0) {
+        const double r0 = __builtin_amdgcn_rcp(d1);
+        const double e0 = __builtin_fma(-d1, r0, 1.0);
+        const double r1 = __builtin_fma(r0, e0, r0);
+        const double e1 = __builtin_fma(-d1, r1, 1.0);
+        const double r2 = __builtin_fma(r1, e1, r1);
+        const double n1 = __builtin_amdgcn_div_scale(x1, y, true, &f1);
+        const double n2 = __builtin_amdgcn_div_scale(x2, y, true, &f2);
+        const double m1 = n1 * r2, m2 = n2 * r2;
+        const double rem1 = __builtin_fma(-d1, m1, n1), rem2 = __builtin_fma(-d1, m2, n2);
+        q1 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(rem1, r2, m1, f1), y, x1);
+        q2 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(rem2, r2, m2, f2), y, x2);
+    } else {
+        q1 = x1 / y;
+        q2 = x2 / y;
+    }
+}
+
 // 2x2 solve + OpenCV-2.4 divide (den == 0 -> 0).  ParallelVideoPyr.cpp:470-472, 510-520.
 // s = {Sxx, Syy, Sxy, Sxt, Syt}
 __device__ __forceinline__ void lk_solve(const double s[5], double &u, double &v)
+{
+    const double det = s[0] * s[1] - s[2] * s[2];
+    const double un = s[2] * s[4] - s[1] * s[3];
+    const double vn = s[3] * s[2] - s[0] * s[4];
+    double qu, qv;
+    lk_div2(un, vn, det, qu, qv);
+    u = det != 0.0 ? qu : 0.0;
+    v = det != 0.0 ? qv : 0.0;
+}
+// the same with two plain divisions (the compiler's expansion): lkflow_solve_f64_dev's cross-check mode
+__device__ __forceinline__ void lk_solve_plain(const double s[5], double &u, double &v)
 {
     const double det = s[0] * s[1] - s[2] * s[2];
     const double un = s[2] * s[4] - s[1] * s[3];
@@ -189,24 +231,31 @@ __device__ __forceinline__ double remap_bilinear(const double *src, int pitch, i
 // gathers fly together (remap_bilinear's conditional loads make it drain vmcnt(0) in front of each one: four serial memory
 // round trips per marched row in a kernel that has only two waves per SIMD to hide them).  Same fixed-point arithmetic,
 // same blend expression: bit-identical to remap_bilinear().
-struct RemapTaps { int sx, sy; int off; };
+// (round 4: the record carries what the blend needs -- the two 5-bit fractions as bytes 0 and 1 of one register, which
+// v_cvt_f32_ubyte0 / 1 convert without an unpack, and the distance of the real tap block from the clamped one -- instead of
+// the raw fixed-point coordinates, from which the blend re-derived both: 12 vector instructions per sample fewer.)
+struct RemapTaps { int fr; int off; int dxy; };   // fractions (sx & 31) | (sy & 31) << 8; element offset of the clamped block; (dx & 0xFFFF) | dy << 16
+template <bool M24 = false>
 __device__ __forceinline__ RemapTaps remap_taps(int pitch, int H, int W, float mx, float my)
 {
     RemapTaps t;
-    t.sx = cv_round_f(mx * 32.0f);
-    t.sy = cv_round_f(my * 32.0f);
-    const int ixc = min(max(sat_short(t.sx >> 5), 0), W - 2), iyc = min(max(sat_short(t.sy >> 5), 0), H - 2);
-    t.off = iyc * pitch + ixc;
+    const int sx = cv_round_f(mx * 32.0f), sy = cv_round_f(my * 32.0f);
+    const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);       // cv::remap keeps the integer parts as shorts
+    const int ixc = min(max(ix, 0), W - 2), iyc = min(max(iy, 0), H - 2);
+    // M24 (host-checked by the launcher: pitch and H below 2^24): full-rate 24-bit multiply instead of v_mul_lo_u32
+    t.off = M24 ? (int)__umul24((unsigned)iyc, (unsigned)pitch) + ixc : iyc * pitch + ixc;
+    t.fr = (sx & 31) | ((sy & 31) << 8);
+    // both differences lie in [-32768, 32767] (ix < 0 -> ixc = 0; ix > W - 2 -> ixc = W - 2 >= 0): they pack into halves
+    t.dxy = ((ix - ixc) & 0xFFFF) | ((iy - iyc) << 16);
     return t;
 }
 typedef double lk_d2u __attribute__((ext_vector_type(2), aligned(8)));
-__device__ __forceinline__ double remap_blend(const RemapTaps &t, lk_d2u top, lk_d2u bot, int H, int W)
+__device__ __forceinline__ double remap_blend(const RemapTaps &t, lk_d2u top, lk_d2u bot, int, int)
 {
-    const int ix = sat_short(t.sx >> 5), iy = sat_short(t.sy >> 5);
-    const int dx = ix - min(max(ix, 0), W - 2), dy = iy - min(max(iy, 0), H - 2);
-    const float a = (float)(t.sx & 31) * (1.0f / 32), b = (float)(t.sy & 31) * (1.0f / 32);
+    const float a = (float)(t.fr & 0xFF) * (1.0f / 32), b = (float)((t.fr >> 8) & 0xFF) * (1.0f / 32);
     const float w0 = (1.0f - b) * (1.0f - a), w1 = (1.0f - b) * a, w2 = b * (1.0f - a), w3 = b * a;
-    if ((dx | dy) != 0) {                                    // some tap of this lane leaves the image (no memory instruction inside)
+    if (t.dxy != 0) {                                        // some tap of this lane leaves the image (no memory instruction inside)
+        const int dx = (int)(short)(t.dxy & 0xFFFF), dy = t.dxy >> 16;
         const lk_d2u z = {0.0, 0.0};
         const lk_d2u t0 = top, t1 = bot;
         top = dy == 0 ? t0 : (dy == 1 ? t1 : z);

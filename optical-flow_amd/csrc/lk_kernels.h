@@ -143,6 +143,122 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(PyrDownArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two pyramid levels in one pass (round 4): level 1 = cv::pyrDown(src) and level 2 = cv::pyrDown(level 1), the level-1 rows
+// going to memory AND, still in registers, through the second filter -- the source is read once and level 1 is never read
+// back (per 1080p frame: 16.6 + 4.1 + 1.0 MB moved instead of 16.6 + 4.1 + 4.1 + 1.0).  Same expressions as pyrdown_kernel at
+// both levels (level 2 is computed from the very doubles that are stored as level 1): bit-identical to two passes.
+// Lane l of wave column w holds level-1 column ox = 58 w + l - 3.  Lanes 1..62 compute level 1 (neighbour source pairs by DPP,
+// as in pyrdown_kernel), lanes 3..60 store it; the level-2 column 2 x2 = ox sits in the ODD lanes 3..59 (29 per wave) and takes
+// its five horizontal taps from lanes l - 2 .. l + 2 by DPP wave shifts: the four extra level-1 columns per wave are the halo
+// of the second filter.  At the left / right image border the halo lanes take the REFLECTED level-1 column from the lane that
+// holds it (reflect-101 of level 1 is not what pyrDown of the reflected source gives).  Vertically a block computes the
+// level-1 rows oy0 - 2 .. oy1 of its strip (stores oy0 .. oy1 - 1) and keeps the last five second-filter rows in registers;
+// the top and bottom image rows use the reflected rows the ring already holds.  Host-checked: W, H multiples of 4 (both levels
+// halve exactly), W / 2 >= 8, H / 2 >= 4, strip height a multiple of 4.
+// ------------------------------------------------------------------------------------------------
+struct PyrDown2Args {
+    CPlanes src;
+    Planes d1, d2;
+    int H, W, H1, W1, H2, W2;
+    int gx, gy;        // tiles per plane
+    int th;            // level-1 rows stored per block (multiple of 4)
+};
+constexpr int PD2_WCOLS = 58;                         // level-1 columns stored per wave (= 29 level-2 columns)
+
+__global__ __launch_bounds__(256) void pyrdown2_kernel(PyrDown2Args a)
+{
+    const unsigned n = gridDim.x;
+    unsigned tile = xcd_tile_id(blockIdx.x, n);
+    const int bx = tile % a.gx; tile /= a.gx;
+    const int by = tile % a.gy;
+    const int plane = tile / a.gy;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wcol = bx * 4 + wave;
+    const int H = a.H, W = a.W, H1 = a.H1, W1 = a.W1;
+    if (wcol * PD2_WCOLS >= W1) return;                     // whole wave outside (wave-uniform)
+    const int ox = wcol * PD2_WCOLS + lane - 3;             // level-1 column of this lane
+    const int oy0 = by * a.th, oy1 = min(oy0 + a.th, H1);   // level-1 rows this block stores (oy0 % 4 == 0, oy1 even)
+    const int rs = max(oy0 - 2, 0), re = min(oy1, H1 - 1);  // level-1 rows it computes (rs even)
+    const double *s = a.src.at(plane);
+    const int pitch = (int)a.src.pitch;
+    const int c0 = 2 * ox;                                  // source columns c0, c0 + 1
+    const bool vec = __all(c0 >= 0 && c0 + 1 < W);          // wave-uniform (see pyrdown_kernel)
+    const int r0c = r101(c0, W), r1c = r101(c0 + 1, W);
+    const int row_lo = max(2 * rs - 2, 0);
+    const __amdgpu_buffer_rsrc_t rS = buf_rsrc(s + (long long)row_lo * pitch, ((long long)(H - 1 - row_lo) * pitch + W) * 8);
+    const int pitchb = pitch * 8;
+    auto ld = [&](int sy, double &cx, double &cy) __attribute__((always_inline)) {
+        const int so = (r101(sy, H) - row_lo) * pitchb;     // row index is wave-uniform
+        if (vec) {
+            typedef unsigned int lk_u4 __attribute__((ext_vector_type(4)));
+            const lk_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rS, c0 * 8, so, LK_PD_LOAD_AUX);
+            cx = __hiloint2double((int)v.y, (int)v.x); cy = __hiloint2double((int)v.w, (int)v.z);
+        } else {
+            cx = buf_ld(rS, r0c * 8, so); cy = buf_ld(rS, r1c * 8, so);
+        }
+    };
+    auto hf = [&](double cx, double cy) __attribute__((always_inline)) -> double {   // level-1 horizontal filter (pyrdown_kernel's)
+        const double lx = dpp_wave_shr1(cx), ly = dpp_wave_shr1(cy), rx = dpp_wave_shl1(cx);
+        return cx * 6 + (ly + cy) * 4 + lx + rx;
+    };
+    // reflect-101 of the LEVEL-1 columns for the second filter: a halo lane outside [0, W1) takes the value of the lane that
+    // holds the reflected column (always in this wave: -1 -> 1, -2 -> 2, W1 -> W1 - 2, W1 + 1 -> W1 - 3)
+    int fsrc = lane;
+    if (ox < 0) fsrc = lane - 2 * ox;
+    if (ox >= W1) fsrc = lane + 2 * (W1 - 1 - ox);
+    fsrc = min(max(fsrc, 0), 63);
+    const bool need_fix = __any(ox < 0 || ox >= W1);        // wave-uniform: first / last wave of a row
+    auto hf2 = [&](double v) __attribute__((always_inline)) -> double {             // level-2 horizontal filter on level-1 lanes
+        if (need_fix) v = __shfl(v, fsrc, 64);
+        const double l1 = dpp_wave_shr1(v), r1 = dpp_wave_shl1(v);
+        const double l2 = dpp_wave_shr1(l1), r2 = dpp_wave_shl1(r1);
+        return v * 6 + (l1 + r1) * 4 + l2 + r2;
+    };
+    const bool st1_lane = lane >= 3 && lane <= 60 && ox < W1;
+    const bool st2_lane = (lane & 1) && lane >= 3 && lane <= 59 && ox < W1;          // ox even: level-2 column ox / 2
+    const int d1pb = (int)a.d1.pitch * 8, d2pb = (int)a.d2.pitch * 8;
+    const __amdgpu_buffer_rsrc_t rD1 = buf_rsrc(a.d1.at(plane) + (long long)oy0 * a.d1.pitch, ((long long)(oy1 - 1 - oy0) * a.d1.pitch + W1) * 8);
+    const int y20 = oy0 >> 1, y21 = oy1 >> 1;               // level-2 rows of this block
+    const __amdgpu_buffer_rsrc_t rD2 = buf_rsrc(a.d2.at(plane) + (long long)y20 * a.d2.pitch, ((long long)(y21 - 1 - y20) * a.d2.pitch + a.W2) * 8);
+    const int vo1 = st1_lane ? ox * 8 : (int)0x80000000, vo2 = st2_lane ? (ox >> 1) * 8 : (int)0x80000000;   // out of range: the store is dropped
+
+    double gm4 = 0, gm3 = 0, gm2 = 0, gm1 = 0, g0 = 0;      // second-filter rows r - 4 .. r of the level-1 row r just made
+    // one finished level-1 row r (wave-uniform): store it, run it through the second filter, emit the level-2 row it completes
+    auto row_done = [&](int r, double v) __attribute__((always_inline)) {
+        if (r >= oy0 && r < oy1) buf_st_cached(rD1, vo1, (r - oy0) * d1pb, v);      // (the LK kernels re-read it soon)
+        gm4 = gm3; gm3 = gm2; gm2 = gm1; gm1 = g0; g0 = hf2(v);
+        if (!(r & 1) && r >= oy0 + 2) {                     // level-2 row (r - 2) / 2: rows r - 4 .. r (top of the image: -2 -> 2, -1 -> 1)
+            const double t4 = r == 2 ? g0 : gm4, t3 = r == 2 ? gm1 : gm3;
+            buf_st_cached(rD2, vo2, (((r - 2) >> 1) - y20) * d2pb, (gm2 * 6 + (t3 + gm1) * 4 + t4 + g0) * (1.0 / 256));
+        }
+        if (r == H1 - 1)                                    // the last level-2 row: rows H1 - 4 .. H1 -> H1 - 2 (H1 is even)
+            buf_st_cached(rD2, vo2, (((H1 >> 1) - 1) - y20) * d2pb, (gm1 * 6 + (gm2 + g0) * 4 + gm3 + gm1) * (1.0 / 256));
+    };
+
+    double ax, ay, bx2, by2, cx2, cy2;
+    ld(2 * rs - 2, ax, ay); ld(2 * rs - 1, bx2, by2); ld(2 * rs, cx2, cy2);
+    double h0 = hf(ax, ay), h1 = hf(bx2, by2), h2 = hf(cx2, cy2);
+    int r = rs;
+    for (; r + 1 <= re; r += 2) {                           // two level-1 rows per iteration: four 16-byte loads in flight per lane
+        double p3x, p3y, p4x, p4y, p5x, p5y, p6x, p6y;
+        ld(2 * r + 1, p3x, p3y); ld(2 * r + 2, p4x, p4y); ld(2 * r + 3, p5x, p5y); ld(2 * r + 4, p6x, p6y);
+        const double h3 = hf(p3x, p3y), h4 = hf(p4x, p4y), h5 = hf(p5x, p5y), h6 = hf(p6x, p6y);
+        const double o0 = (h2 * 6 + (h1 + h3) * 4 + h0 + h4) * (1.0 / 256);
+        const double o1 = (h4 * 6 + (h3 + h5) * 4 + h2 + h6) * (1.0 / 256);
+        row_done(r, o0);
+        row_done(r + 1, o1);
+        h0 = h4; h1 = h5; h2 = h6;
+    }
+    if (r <= re) {
+        double p3x, p3y, p4x, p4y;
+        ld(2 * r + 1, p3x, p3y); ld(2 * r + 2, p4x, p4y);
+        const double h3 = hf(p3x, p3y), h4 = hf(p4x, p4y);
+        row_done(r, (h2 * 6 + (h1 + h3) * 4 + h0 + h4) * (1.0 / 256));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // cv::pyrUp as a stand-alone stage (tests / API); the pipeline evaluates pyrup_at() inside the
 // warp and LK kernels instead of materialising the up-sampled flow.
 // ------------------------------------------------------------------------------------------------
@@ -180,6 +296,8 @@ struct WarpArgs {
 #ifndef LK_WARP_WAVES
 #define LK_WARP_WAVES 1
 #endif
+// M24: the launcher has checked that the image pitch and height are below 2^24 (24-bit multiplies in the tap addresses)
+template <bool M24>
 __global__ __launch_bounds__(256, LK_WARP_WAVES) void warp_kernel(WarpArgs a)
 {
     const unsigned n = gridDim.x;
@@ -240,8 +358,8 @@ __global__ __launch_bounds__(256, LK_WARP_WAVES) void warp_kernel(WarpArgs a)
         // all four gathers in flight before the first store (H is even: row y+1 exists)
 #if LK_WARP_UNCOND
         // all eight gathers of the row pair unconditionally and up front (lk_device.h remap_taps / remap_blend: bit-identical)
-        const RemapTaps ta0 = remap_taps(ip, H, W, xf + hx0, yf0 + hy0), tb0 = remap_taps(ip, H, W, xf - hx0, yf0 - hy0);
-        const RemapTaps ta1 = remap_taps(ip, H, W, xf + hx1, yf1 + hy1), tb1 = remap_taps(ip, H, W, xf - hx1, yf1 - hy1);
+        const RemapTaps ta0 = remap_taps<M24>(ip, H, W, xf + hx0, yf0 + hy0), tb0 = remap_taps<M24>(ip, H, W, xf - hx0, yf0 - hy0);
+        const RemapTaps ta1 = remap_taps<M24>(ip, H, W, xf + hx1, yf1 + hy1), tb1 = remap_taps<M24>(ip, H, W, xf - hx1, yf1 - hy1);
         const lk_d2u g0 = *reinterpret_cast<const lk_d2u *>(I1 + ta0.off), g1 = *reinterpret_cast<const lk_d2u *>(I1 + ta0.off + ip);
         const lk_d2u g2 = *reinterpret_cast<const lk_d2u *>(I2 + tb0.off), g3 = *reinterpret_cast<const lk_d2u *>(I2 + tb0.off + ip);
         const lk_d2u g4 = *reinterpret_cast<const lk_d2u *>(I1 + ta1.off), g5 = *reinterpret_cast<const lk_d2u *>(I1 + ta1.off + ip);
@@ -722,6 +840,23 @@ __global__ __launch_bounds__(256) void u8_to_f64_kernel(const unsigned char *src
     }
     for (size_t j = 2 * npair + (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
         dst[j] = (double)src[j] * (1.0 / 255);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 2 x 2 solve + cv::divide of a6 (ParallelVideoPyr.cpp:470-472, 510-520) as a stage of its own: S = five planes of n window
+// sums (Sxx, Syy, Sxy, Sxt, Syt).  plain = 0: lk_solve (what every LK kernel runs: both quotients from one reciprocal iteration),
+// plain = 1: two compiler-expanded IEEE divisions -- the pair must agree bit for bit on every input class.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void solve_kernel(const double *S, size_t n, double *u, double *v, int plain)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double s[5] = {S[i], S[n + i], S[2 * n + i], S[3 * n + i], S[4 * n + i]};
+        double a, b;
+        if (plain) lk_solve_plain(s, a, b);
+        else lk_solve(s, a, b);
+        u[i] = a; v[i] = b;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -306,7 +306,8 @@ __global__ __launch_bounds__(TX, (WIN <= 15 ? 2 : 1)) void lk_march3_kernel(LKAr
                 const double un = S[2] * S[4] - S[1] * S[3];
                 const double vn = S[3] * S[2] - S[0] * S[4];
                 const bool nz = det != 0.0;                    // cv::divide: x/0 -> 0
-                const double qu = un / det, qv = vn / det;
+                double qu, qv;
+                lk_div2(un, vn, det, qu, qv);
                 u = nz ? qu : 0.0;
                 v = nz ? qv : 0.0;
             }

@@ -128,7 +128,7 @@ struct SplitCfg {
     // F is the wave that paces a workgroup and S has slack: S adds (4K/L5/w21 28.4 -> 30.2 Gpx/s).  From 23 x 23 on (one
     // workgroup per CU, 16 LDS reads per row and field) the S waves' LDS reads are the longer pole: halving their bytes
     // wins (8K/L5/w31: level-0 LK 2.20 -> 2.08 ms; profiles/r02_j_qsum_ab.txt).
-    static constexpr bool QSUM = WIN > LK_SPLIT_QSUM_ABOVE && WIN > LK_SPLIT_TWO_WG_MAX;
+    static constexpr bool QSUM = !FW && WIN > LK_SPLIT_QSUM_ABOVE && WIN > LK_SPLIT_TWO_WG_MAX;   // (fused warp: S sums as the shifted pair sums arrive, at any window)
     static constexpr int UN = PF >= 4 ? PF / 2 : 2;  // unrolled F group in steps: even (LDS buffer parity) and PF rows (queue slots)
     static_assert(K == 2, "one F wave feeds 126 columns: S lanes own 2 columns (K = 4 ran one 11-wave block per CU: slower)");
     static_assert(PSTR >= NJP, "product half-planes must not overlap");
@@ -363,8 +363,14 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     // 16-byte LDS reads per sample instead of 16 vector instructions (and / cvt / mul / sub / 4 mul / 4 cvt)
     __shared__ __attribute__((aligned(16))) double s_wt[FW ? 1024 : 1][FW ? 4 : 1];
 
-    // logical wave (role order B, S, F) of the physical wave: the role -> SIMD placement is an A/B knob (-DLK_SPLIT_PERM=...)
-    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // logical wave (role order B, S, F, W) of the physical wave.  A workgroup's waves are dealt to the CU's four SIMDs cyclically
+    // (physical waves p, p + 4, p + 8 ... share one), so for the fused kernel's 12 or 13 waves a table (-DLK_SPLIT_FW_PERM, one hex
+    // digit per physical wave, wave 0 lowest) chooses which roles share a SIMD; 0 = role order
+#ifndef LK_SPLIT_FW_PERM
+#define LK_SPLIT_FW_PERM 0
+#endif
+    const int pwv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wv = (FW && LK_SPLIT_FW_PERM != 0) ? (int)(((unsigned long long)LK_SPLIT_FW_PERM >> (4 * pwv)) & 15) : pwv;
     const int ltid = wv * 64 + ((int)threadIdx.x & 63);   // thread index in role order
     // 1-D grid, XCD-aware tile order (lk_kernels.h): workgroups are dealt round-robin over the 8 XCDs (private L2s), so
     // with the natural order the column blocks of one strip -- which share 2 HL halo columns -- and vertically adjacent
@@ -837,11 +843,8 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             const double un = S[2] * S[4] - S[1] * S[3];
             const double vn = S[3] * S[2] - S[0] * S[4];
             const bool nz = det != 0.0;                     // cv::divide: x/0 -> 0
-#ifdef LK_ABL_B   /* timing-only ablation: results wrong */
-            const double qu = un + det, qv = vn + det;
-#else
-            const double qu = un / det, qv = vn / det;
-#endif
+            double qu, qv;
+            lk_div2(un, vn, det, qu, qv);                   // both quotients correctly rounded, one reciprocal iteration (lk_device.h)
             u = nz ? qu : 0.0;
             v = nz ? qv : 0.0;
         };
@@ -989,12 +992,21 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         auto ssum = [&](auto kc, const SRow &r, double (&S)[K]) __attribute__((always_inline)) {
             constexpr int KC = decltype(kc)::value;
             double hs[K];
+            // the part the two windows share: up to 21 x 21 a tree over the pair sums; above, centre outwards, left before right --
+            // the order in which the STREAMED form meets them -- in EVERY form of the kernel (published pair sums at 29 x 29 and
+            // 31 x 31, fused warp, LK_SPLIT_QDPP = 0), so that a window's bits do not depend on which form a level's size selects
+            double shared;
+            if constexpr (STREAMED) shared = r.q[QH];
+            else if constexpr (WIN > 21) {
+                shared = r.q[QH];
+#pragma unroll
+                for (int d = 1; d <= QH; ++d)
+                    if (RODD || d < QH) shared = (shared + r.q[QH - d]) + r.q[QH + d];
+            } else shared = RODD ? split_tree<0, NQ - 1>(r.q) : split_tree<1, NQ - 2>(r.q);
             if constexpr (RODD) {
-                const double shared = STREAMED ? r.q[QH] : split_tree<0, NQ - 1>(r.q);
                 hs[0] = r.sb + shared;
                 hs[1] = shared + r.sa;
             } else {
-                const double shared = STREAMED ? r.q[QH] : split_tree<1, NQ - 2>(r.q);
                 hs[0] = (r.q[0] + shared) + r.sa;
                 hs[1] = (r.sb + shared) + r.q[NQ - 1];
             }

@@ -17,6 +17,7 @@ namespace lk {
 
 constexpr int W3X1_XO = 61;                     // output columns per wave: lanes 2..62
 
+template <bool M24>      // the launcher has checked that the image pitch and height are below 2^24 (24-bit multiplies in the tap addresses)
 __global__ __launch_bounds__(64, 3) void lk_w3x1f_kernel(LKArgs a)
 {
     constexpr int WIN = 3, R = 1;
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(64, 3) void lk_w3x1f_kernel(LKArgs a)
     auto issue = [&](int yw, double uu, double vv, Fly &g) __attribute__((always_inline)) {   // warp_kernel's map build, float32
         const float yf = (float)yw;
         const float hx = (float)uu / 2, hy = (float)vv / 2;
-        g.t1 = remap_taps(ip, H, W, xf + hx, yf + hy);
-        g.t2 = remap_taps(ip, H, W, xf - hx, yf - hy);
+        g.t1 = remap_taps<M24>(ip, H, W, xf + hx, yf + hy);
+        g.t2 = remap_taps<M24>(ip, H, W, xf - hx, yf - hy);
         g.a0 = *reinterpret_cast<const lk_d2u *>(I1 + g.t1.off); g.a1 = *reinterpret_cast<const lk_d2u *>(I1 + g.t1.off + ip);
         g.b0 = *reinterpret_cast<const lk_d2u *>(I2 + g.t2.off); g.b1 = *reinterpret_cast<const lk_d2u *>(I2 + g.t2.off + ip);
     };
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(64, 3) void lk_w3x1f_kernel(LKArgs a)
 
         if (out_row && is_out) {                                // flow of row y = yw - 2: its pyrUp term sits in d2*
             double u = 0.0, v = 0.0;
-            if (y >= 1 && y <= H - 2 && xa >= 1 && xa <= W - 2) lk_solve(S, u, v);
+            if (y >= 1 && y <= H - 2 && xa >= 1 && xa <= W - 2) lk_solve_plain(S, u, v);   // (two plain divisions: the shared-reciprocal form needs 4 more registers than this kernel has at 3 waves per SIMD; same bits)
             buf_st(rU, vxo, (y - y0) * upb, u + d2u);
             buf_st(rV, vxo, (y - y0) * vpb, v + d2v);
         }

@@ -433,7 +433,7 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s, i
     return LKFLOW_OK;
 }
 
-#define LKFLOW_SPLIT_FUSED_MAX_WIN 21                // 12-wave workgroups, one per CU: <= 168 VGPRs (bigger rings: not built)
+#define LKFLOW_SPLIT_FUSED_MAX_WIN 31                // 12-wave workgroups, one per CU: <= 168 VGPRs
 bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H, int pairs);
 
 int launch_splitw(lkflow_ctx *ctx, const lk::LKArgs &a, int pairs, int win, hipStream_t s, int level)
@@ -441,9 +441,13 @@ int launch_splitw(lkflow_ctx *ctx, const lk::LKArgs &a, int pairs, int win, hipS
     switch (win) {
 #define SP_CASE(WN) case WN: return launch_splitw_win<WN, 2>(ctx, a, pairs, s, level);
 #ifdef LKFLOW_FAST_BUILD
-        SP_CASE(15) SP_CASE(21)
+        SP_CASE(15) SP_CASE(21) SP_CASE(31)
+#ifdef LKFLOW_FAST_WINS_EXTRA
+        SP_CASE(23) SP_CASE(25) SP_CASE(27) SP_CASE(29)
+#endif
 #else
         SP_CASE(5) SP_CASE(7) SP_CASE(9) SP_CASE(11) SP_CASE(13) SP_CASE(15) SP_CASE(17) SP_CASE(19) SP_CASE(21)
+        SP_CASE(23) SP_CASE(25) SP_CASE(27) SP_CASE(29) SP_CASE(31)
 #endif
 #undef SP_CASE
         default: return LK_NOT_TAKEN;
@@ -461,18 +465,19 @@ bool split_applies(int win, int W, int H)
 // Windows 5..21 on even levels: run the warp of the level inside the wave-specialised LK kernel (lk_split.h, W role: the warped
 // planes never reach memory)?  LKFLOW_OPT_FUSE_WARP 1: wherever the kernel takes the shape; 2 (default): where it was measured
 // faster than warp + LK -- levels of at least 256 rows (a 12-wave workgroup has a CU to itself and marches a tall strip: its
-// pipeline fill and its weight table are paid per strip) with at least half a column block per CU (32 x 1080p: level 0
-// 1.09 -> 1.01 ms, level 1 0.319 -> 0.312; 8 x 3840x2160 / w21: 1.14 -> 1.07; the 245-frame 240 x 160 stream: 0.23 -> 0.27,
-// hence not there: profiles/r04_a_fused_warp_ab.txt).
+// pipeline fill and its weight table are paid per strip; 32 x 1080p: level 0 1.09 -> 1.01 ms, level 1 0.319 -> 0.312; one pair:
+// whole step 0.134 -> 0.122 ms; 8 x 3840x2160 at 21 x 21: 1.14 -> 1.07, at 31 x 31 -- where the unfused kernel runs one workgroup
+// per CU as well -- 2.70 -> 2.29; the 245-frame 240 x 160 stream: 0.23 -> 0.27, hence not there: profiles/r04_a_fused_warp_ab.txt).
 bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H, int pairs)
 {
     static const int env = knob("LKFLOW_SPLIT_FUSED", -1);       // A/B: overrides the option
     const int mode = env >= 0 ? env : ctx->fuse_warp;
     if (!mode || ctx->impl != 0 || win > LKFLOW_SPLIT_FUSED_MAX_WIN || !split_applies(win, W, H)) return false;
     if (mode == 1) return true;
-    using C15 = lk::SplitCfg<15, 2, true>;                       // (XO depends on the window; this is only a size rule)
-    const long long col_blocks = (long long)((W + C15::XO - 1) / C15::XO) * pairs;
-    return H >= 256 && 2 * col_blocks >= ctx->n_cu;
+    (void)pairs;                                                 // (1, 4 and 32 pairs of 1080p all gain: the rule is the level's height)
+    // 29 x 29 and 31 x 31 run one workgroup per CU unfused as well: fused wins from 256 rows on; up to 15 x 15 a 540-row level is a
+    // wash (0.308 fused against 0.299 for 32 x 960 x 540), 1080 rows gain 7 %
+    return H >= (win >= 29 ? 256 : (win >= 17 ? 512 : 768));
 }
 
 // LK_NOT_TAKEN: this window has no wave-specialised instantiation
@@ -596,11 +601,11 @@ int launch_w3x2f(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
 #ifdef LKFLOW_EXPERIMENTAL
     static const int one_col = knob("LKFLOW_W3_ONE_COLUMN", LKFLOW_W3_ONE_COLUMN);   // A/B
     const int xo = one_col ? lk::W3X1_XO : lk::W3X2_XO;
-    const int bpc = one_col ? blocks_per_cu(ctx, lk::lk_w3x1f_kernel, 64) : blocks_per_cu(ctx, lk::lk_w3x2f_kernel, 64);
+    const int bpc = one_col ? blocks_per_cu(ctx, lk::lk_w3x1f_kernel<true>, 64) : blocks_per_cu(ctx, lk::lk_w3x2f_kernel, 64);
 #else
     constexpr int one_col = 1;
     const int xo = lk::W3X1_XO;
-    const int bpc = blocks_per_cu(ctx, lk::lk_w3x1f_kernel, 64);
+    const int bpc = blocks_per_cu(ctx, lk::lk_w3x1f_kernel<true>, 64);
 #endif
     const int gx = (a.W + xo - 1) / xo;
     int th = ctx->tile_rows > 0 ? ctx->tile_rows : pick_tile_rows(a.H, 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
@@ -612,7 +617,8 @@ int launch_w3x2f(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s)
         if (th > cap) th = (int)cap;
     }
     a.th = th;
-    if (one_col) hipLaunchKernelGGL(lk::lk_w3x1f_kernel, dim3(gx, (a.H + th - 1) / th, pairs), dim3(64), 0, s, a);
+    if (one_col && a.i1.pitch < (1 << 24) && a.H < (1 << 24)) hipLaunchKernelGGL(lk::lk_w3x1f_kernel<true>, dim3(gx, (a.H + th - 1) / th, pairs), dim3(64), 0, s, a);
+    else if (one_col) hipLaunchKernelGGL(lk::lk_w3x1f_kernel<false>, dim3(gx, (a.H + th - 1) / th, pairs), dim3(64), 0, s, a);
 #ifdef LKFLOW_EXPERIMENTAL
     else hipLaunchKernelGGL(lk::lk_w3x2f_kernel, dim3(gx, (a.H + th - 1) / th, pairs), dim3(64), 0, s, a);
 #endif
@@ -691,6 +697,33 @@ int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int p
     return LKFLOW_OK;
 }
 
+// Levels 1 and 2 of a pyramid in one pass over level 0 (lk_kernels.h pyrdown2_kernel).  LK_NOT_TAKEN: shape not taken (the
+// caller runs two single-level passes): both levels must halve exactly and be big enough for the in-wave reflections.
+#ifndef LK_PD2_TH
+#define LK_PD2_TH 64
+#endif
+bool pyrdown2_applies(int H, int W)
+{
+    static const int on = knob("LKFLOW_PD2", 1);              // A/B: 0 = two passes
+    return on && H % 4 == 0 && W % 4 == 0 && W / 2 >= 8 && H / 2 >= 4;
+}
+int launch_pyrdown2(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes d1, Planes d2, int planes, hipStream_t s)
+{
+    if (!pyrdown2_applies(H, W)) return LK_NOT_TAKEN;
+    lk::PyrDown2Args a{};
+    a.src = src; a.d1 = d1; a.d2 = d2; a.H = H; a.W = W;
+    a.H1 = H / 2; a.W1 = W / 2; a.H2 = H / 4; a.W2 = W / 4;
+    a.th = LK_PD2_TH;
+    { static const int e = knob("LKFLOW_PD2_TH", 0); if (e > 0) a.th = (e + 3) & ~3; }
+    a.gx = (a.W1 + 4 * lk::PD2_WCOLS - 1) / (4 * lk::PD2_WCOLS); a.gy = (a.H1 + a.th - 1) / a.th;
+    if ((long long)(2 * a.th + 16) * 8 * std::max(src.pitch, std::max(d1.pitch, d2.pitch)) > 0x7fffffffLL) return LK_NOT_TAKEN;   // strip-relative 32-bit offsets
+    const long long n = (long long)a.gx * a.gy * planes;
+    if (n > 0x7fffffffLL) return LK_NOT_TAKEN;
+    hipLaunchKernelGGL(lk::pyrdown2_kernel, dim3((unsigned)n), dim3(256), 0, s, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
+}
+
 int launch_warp(lkflow_ctx *ctx, CPlanes i1, CPlanes i2, int H, int W, CPlanes cu, CPlanes cv,
                 Planes o1, Planes o2, int pairs, hipStream_t s)
 {
@@ -707,7 +740,8 @@ int launch_warp(lkflow_ctx *ctx, CPlanes i1, CPlanes i2, int H, int W, CPlanes c
         return LKFLOW_E_ARG;                      // strip-relative 32-bit byte offsets
     const long long n = (long long)a.gx * a.gy * pairs;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
-    hipLaunchKernelGGL(lk::warp_kernel, dim3((unsigned)n), dim3(256), 0, s, a);
+    if (i1.pitch < (1 << 24) && H < (1 << 24)) hipLaunchKernelGGL(lk::warp_kernel<true>, dim3((unsigned)n), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lk::warp_kernel<false>, dim3((unsigned)n), dim3(256), 0, s, a);
     HIP_TRY(ctx, hipGetLastError());
     return LKFLOW_OK;
 }
@@ -753,7 +787,7 @@ int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok,
     static const bool no_fused = (knob("LKFLOW_NO_W3_FUSED", 0) | knob("LKFLOW_NO_W3X2", 0)) != 0;
     static const bool no_x2 = knob("LKFLOW_NO_W3X2", 0) != 0;
     if (win == 3 && has_up && fused_ok && !no_fused && cols >= 2 && !(cols & 1) && !(rows & 1))
-        snprintf(buf, n, "%s", knob("LKFLOW_W3_ONE_COLUMN", LKFLOW_W3_ONE_COLUMN) ? "lk::lk_w3x1f_kernel" : "lk::lk_w3x2f_kernel");
+        snprintf(buf, n, "%s", knob("LKFLOW_W3_ONE_COLUMN", LKFLOW_W3_ONE_COLUMN) ? "lk::lk_w3x1f_kernel<true>" : "lk::lk_w3x2f_kernel");
     else if (win == 3 && !no_x2 && cols >= 2 && !(cols & 1)) snprintf(buf, n, "lk::lk_w3x2_kernel<%s>", up);
     else if (win == 3) snprintf(buf, n, "lk::lk_march3_kernel<3, 64, %s>", up);
     else if (split_applies(win, cols, rows)) {
@@ -990,8 +1024,20 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
     };
     auto as_c = [](Planes p) { return CPlanes{p.base, p.plane, p.pitch}; };
 
-    // a2: Gaussian pyramids of both frames (built from the ORIGINAL images, before any warp)
-    for (int l = 1; l < L; ++l) {
+    // a2: Gaussian pyramids of both frames (built from the ORIGINAL images, before any warp).  Levels 1 and 2 come out of ONE
+    // pass over level 0 where the shape allows (pyrdown2_kernel: level 1 is never read back)
+    int l_first = 1;
+    if (L >= 3 && pyrdown2_applies(lv[0].H, lv[0].W)) {
+        ProfScope ps(ctx, LKFLOW_STAGE_PYRDOWN, 1, s);          // (levels 1 + 2: there is no separate level-2 record)
+        int rc2 = LKFLOW_OK;
+        if (video) rc2 = launch_pyrdown2(ctx, pyr(0, 0), lv[0].H, lv[0].W, pyr_w(1, 0), pyr_w(2, 0), P + 1, s);
+        else
+            for (int f = 0; f < 2 && rc2 == LKFLOW_OK; ++f)
+                rc2 = launch_pyrdown2(ctx, pyr(0, f), lv[0].H, lv[0].W, pyr_w(1, f), pyr_w(2, f), P, s);
+        if (rc2 == LKFLOW_OK) l_first = 3;
+        else if (rc2 != LK_NOT_TAKEN) return rc2;               // (not taken -- offsets too large for the strip -- : two passes below)
+    }
+    for (int l = l_first; l < L; ++l) {
         if (l == 1) {
             ProfScope ps(ctx, LKFLOW_STAGE_PYRDOWN, 1, s);
             if (video) {                                  // P+1 frames, one launch
@@ -1226,6 +1272,23 @@ int lkflow_pyrdown_f64_dev(lkflow_ctx *ctx, const double *src, size_t src_ps, in
                           n_planes, (hipStream_t)stream);
 }
 
+int lkflow_pyrdown2_f64_dev(lkflow_ctx *ctx, const double *src, size_t src_ps, int n_planes, int rows, int cols,
+                            size_t src_step_bytes, double *dst1, size_t dst1_ps, size_t dst1_step_bytes, double *dst2,
+                            size_t dst2_ps, size_t dst2_step_bytes, void *stream)
+{
+    if (!ctx || !src || !dst1 || !dst2 || rows < 1 || cols < 1 || n_planes < 1 || n_planes > 65535) return LKFLOW_E_ARG;
+    if (src_step_bytes < (size_t)cols * 8 || src_step_bytes % 8 || src_ps % 8 || dst1_ps % 8 || dst2_ps % 8) return LKFLOW_E_ARG;
+    if (rows % 4 || cols % 4 || cols / 2 < 8 || rows / 2 < 4) return LKFLOW_E_ARG;            // (the shapes the fused pass takes)
+    if (dst1_step_bytes < (size_t)(cols / 2) * 8 || dst1_step_bytes % 8 || dst2_step_bytes < (size_t)(cols / 4) * 8 || dst2_step_bytes % 8)
+        return LKFLOW_E_ARG;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    rc = launch_pyrdown2(ctx, CPlanes{src, (long long)(src_ps / 8), (long long)(src_step_bytes / 8)}, rows, cols,
+                         Planes{dst1, (long long)(dst1_ps / 8), (long long)(dst1_step_bytes / 8)},
+                         Planes{dst2, (long long)(dst2_ps / 8), (long long)(dst2_step_bytes / 8)}, n_planes, (hipStream_t)stream);
+    return rc == LK_NOT_TAKEN ? LKFLOW_E_ARG : rc;
+}
+
 int lkflow_pyrup_f64_dev(lkflow_ctx *ctx, const double *src, size_t src_ps, int n_planes, int rows,
                          int cols, size_t src_step_bytes, double *dst, size_t dst_ps,
                          size_t dst_step_bytes, void *stream)
@@ -1263,6 +1326,19 @@ int lkflow_warp_f64_dev(lkflow_ctx *ctx, const double *img1, const double *img2,
     return launch_warp(ctx, CPlanes{img1, ip, is}, CPlanes{img2, ip, is}, rows, cols, CPlanes{cu, cp, cs},
                        CPlanes{cv, cp, cs}, Planes{out1, op, os}, Planes{out2, op, os}, n_pairs,
                        (hipStream_t)stream);
+}
+
+int lkflow_solve_f64_dev(lkflow_ctx *ctx, const double *S, size_t n, double *u, double *v, int plain_divisions, void *stream)
+{
+    if (!ctx || !S || !u || !v || plain_divisions < 0 || plain_divisions > 1) return LKFLOW_E_ARG;
+    if (n == 0) return LKFLOW_OK;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(lk::solve_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, S, n, u, v, plain_divisions);
+    HIP_TRY(ctx, hipGetLastError());
+    return LKFLOW_OK;
 }
 
 int lkflow_u8_to_f64_dev(lkflow_ctx *ctx, const unsigned char *src, double *dst, size_t n, void *stream)

@@ -52,7 +52,7 @@ SIGNATURES = {
     "lkflow_strerror": (ctypes.c_char_p, [_i]),
     "lkflow_last_error": (ctypes.c_char_p, [_vp]),
     "lkflow_version": (ctypes.c_char_p, []),
-    "lkflow_lk_kernel_name": (_i, [_i, _i, _i, _i, _i, ctypes.c_char_p, ctypes.c_size_t]),
+    "lkflow_lk_kernel_name": (_i, [_i, _i, _i, _i, _i, _i, ctypes.c_char_p, ctypes.c_size_t]),
     "lkflow_ctx_create": (_i, [ctypes.POINTER(_vp), _i]),
     "lkflow_ctx_destroy": (None, [_vp]),
     "lkflow_ctx_reserve": (_i, [_vp, _i, _i, _i, _i]),
@@ -73,9 +73,11 @@ SIGNATURES = {
                                         _i, _vp]),
     "lkflow_pyrdown_f64_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _vp, _sz, _sz, _vp]),
     "lkflow_pyrup_f64_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _vp, _sz, _sz, _vp]),
+    "lkflow_pyrdown2_f64_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp]),
     "lkflow_warp_f64_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _vp, _vp, _sz, _sz, _vp, _vp,
                                  _sz, _sz, _vp]),
     "lkflow_u8_to_f64_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "lkflow_solve_f64_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _i, _vp]),
     "lkflow_blur_gray_bgr8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _i, _d, _vp, _sz, _sz, _vp]),
     "lkflow_resize_cubic_bgr8_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _sz, _vp, _sz, _i, _i, _sz, _vp]),
     "lkflow_frame_diff_u8_dev": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _sz, _d, _vp, _sz, _sz, _vp]),
@@ -405,6 +407,18 @@ class Context:
                                                dst.stride(1) * 8, _stream_ptr(stream)))
         return dst
 
+    def pyrdown2(self, src, stream=None):
+        """Two pyramid levels in one pass: src [N, H, W] (H, W multiples of 4) -> ([N, H/2, W/2], [N, H/4, W/4])."""
+        torch = _torch()
+        _check_dev(src, "src")
+        N, H, W = src.shape
+        d1 = torch.empty((N, H // 2, W // 2), dtype=torch.float64, device=src.device)
+        d2 = torch.empty((N, H // 4, W // 4), dtype=torch.float64, device=src.device)
+        self._chk(lib().lkflow_pyrdown2_f64_dev(self._h, src.data_ptr(), src.stride(0) * 8, N, H, W, src.stride(1) * 8,
+                                                d1.data_ptr(), d1.stride(0) * 8, d1.stride(1) * 8, d2.data_ptr(),
+                                                d2.stride(0) * 8, d2.stride(1) * 8, _stream_ptr(stream)))
+        return d1, d2
+
     def pyrup(self, src, stream=None):
         torch = _torch()
         _check_dev(src, "src")
@@ -431,6 +445,17 @@ class Context:
             cu.data_ptr(), cv.data_ptr(), cu.stride(0) * 8, cu.stride(1) * 8, o1.data_ptr(),
             o2.data_ptr(), o1.stride(0) * 8, o1.stride(1) * 8, _stream_ptr(stream)))
         return o1, o2
+
+    def solve(self, S, plain=False, stream=None):
+        """a6 as a stage: S [5, n] float64 CUDA tensor of window sums -> (u, v) [n]; plain=True: two IEEE divisions."""
+        torch = _torch()
+        _check_dev(S, "S")
+        assert S.dim() == 2 and S.shape[0] == 5 and S.is_contiguous()
+        n = S.shape[1]
+        u = torch.empty(n, dtype=torch.float64, device=S.device); v = torch.empty_like(u)
+        self._chk(lib().lkflow_solve_f64_dev(self._h, S.data_ptr(), n, u.data_ptr(), v.data_ptr(), int(bool(plain)),
+                                             _stream_ptr(stream)))
+        return u, v
 
     def u8_to_f64(self, src, stream=None):
         torch = _torch()

@@ -163,22 +163,28 @@ def test_two_contexts_pinning_the_same_host_buffers(lkflow, oracle, table_u8, to
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,cols,levels,win", [(136, 240, 3, 15), (272, 480, 3, 9), (96, 300, 2, 5), (540, 960, 3, 13), (272, 480, 3, 21),
-                                                (544, 960, 5, 21), (136, 240, 2, 17), (64, 96, 2, 19), (1080, 1920, 3, 15)])
+                                                (544, 960, 5, 21), (136, 240, 2, 17), (64, 96, 2, 19), (1080, 1920, 3, 15), (272, 480, 3, 23), (272, 480, 3, 25),
+                                                (544, 960, 4, 27), (272, 480, 3, 29), (544, 960, 5, 31), (1080, 1920, 3, 31)])
 def test_fused_warp_option_is_bit_identical(lkflow, torch, rows, cols, levels, win):
-    """LKFLOW_OPT_FUSE_WARP (the warp inside the wave-specialised LK kernel: W role of lk_split.h, lk_border_kernel<., true>)
-    gives the bits of warp_kernel + lk_split_kernel: same pyrUp / map / remap / window-sum expressions in the same order."""
+    """LKFLOW_OPT_FUSE_WARP (the warp inside the wave-specialised LK kernel: W role of lk_split.h, frame pixels by
+    lk_border_pixel<., true> in trailing workgroups) gives the bits of warp_kernel + lk_split_kernel for every window 5..31: same
+    pyrUp / map / remap / window-sum expressions in the same order.  Modes 0 (never), 1 (wherever the shape is taken) and 2
+    (default: by level size) must agree bit for bit."""
     import synth
     fr = [synth.frame_pair(rows, cols, seed=11 + k, shift=(1.7 + 0.4 * k, -0.9)) for k in range(3)]
     a = torch.from_numpy(np.ascontiguousarray(np.stack([f[0] for f in fr]))).cuda()
     b = torch.from_numpy(np.ascontiguousarray(np.stack([f[1] for f in fr]))).cuda()
     with lkflow.Context(0) as ctx:
-        U0, V0 = ctx.compute_batch(a, b, levels, win)
-        ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, 1)
-        U1, V1 = ctx.compute_batch(a, b, levels, win)
         ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, 0)
+        U0, V0 = ctx.compute_batch(a, b, levels, win)          # warp_kernel + lk_split_kernel
+        ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, 1)
+        U1, V1 = ctx.compute_batch(a, b, levels, win)          # fused wherever the kernel takes the shape
+        ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, 2)
+        U2, V2 = ctx.compute_batch(a, b, levels, win)          # the default: fused where it was measured faster
         torch.cuda.synchronize()
     assert float(U0.abs().max()) > 0.1                     # the pair really moves
     assert torch.equal(U0, U1) and torch.equal(V0, V1)
+    assert torch.equal(U0, U2) and torch.equal(V0, V2)
 
 
 @pytest.mark.gpu

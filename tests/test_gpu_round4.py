@@ -170,3 +170,63 @@ def test_edge_map_crop_big_windows_absolute_bar(gpu_ctx, lkflow, oracle, edge_st
         assert float(en.max()) == 0.0                                  # same order as the oracle: same bits
         assert int(bad.sum()) == 0, (p, int(bad.sum()), float(e.max()))
     print(f"edge crop L{levels} w{win}: every pixel within {worst_good:.3e} of the oracle")
+
+
+# ---------------------------------------------------------------------------- the solve: shared-reciprocal divisions
+def test_solve_shared_reciprocal_is_correctly_rounded(gpu_ctx, oracle, torch):
+    """a6 (ParallelVideoPyr.cpp:470-472, 510-520): every LK kernel forms un / det and vn / det from ONE reciprocal iteration
+    (lk_device.h lk_div2).  On 1e7 random sum quintuples spread over the whole exponent range, on denormal and huge
+    determinants, zeros, infinities and NaNs: bit-identical to two independent IEEE divisions on the GPU, and to NumPy's
+    correctly rounded float64 division."""
+    rng = np.random.default_rng(2024)
+    n = 10_000_000
+    S = np.empty((5, n))
+    for f in range(5):
+        mant = rng.uniform(1.0, 2.0, n) * np.where(rng.random(n) < 0.5, -1.0, 1.0)
+        expo = rng.integers(-40, 41, n) if f < 3 else rng.integers(-500, 501, n)
+        S[f] = np.ldexp(mant, expo)
+    S[0] = np.abs(S[0]); S[1] = np.abs(S[1])                                  # Sxx, Syy are sums of squares
+    k = n // 10
+    S[2, :k] = np.sqrt(S[0, :k] * S[1, :k]) * (1 + rng.integers(-4, 5, k) * 2.0 ** -52)   # det = residue of two nearly equal products
+    S[0, k:2 * k] = np.ldexp(rng.uniform(1, 2, k), rng.integers(-540, -500, k))            # denormal / tiny determinants
+    S[1, k:2 * k] = np.ldexp(rng.uniform(1, 2, k), rng.integers(-540, -500, k)); S[2, k:2 * k] = 0.0
+    S[0, 2 * k:3 * k] = np.ldexp(rng.uniform(1, 2, k), rng.integers(400, 511, k))          # huge determinants, tiny numerators
+    S[1, 2 * k:3 * k] = np.ldexp(rng.uniform(1, 2, k), rng.integers(400, 511, k)); S[2, 2 * k:3 * k] = 0.0
+    S[3, 2 * k:3 * k] = np.ldexp(rng.uniform(1, 2, k), rng.integers(-1000, -600, k))
+    S[:, 3 * k:3 * k + 8] = np.array([[0, 0, 0, 1, 1], [1, 1, 1, 2, 3], [np.inf, 1, 0, 1, 1], [1, 1, 0, np.nan, 1], [4, 4, 4, 0, 0],
+                                      [1, 1, 0, 0, 0], [5e-324, 1, 0, 1, 1], [1e308, 1e308, 0, 1, 1]]).T
+    d = dev(torch, S)
+    u0, v0 = gpu_ctx.solve(d)
+    u1, v1 = gpu_ctx.solve(d, plain=True)
+    u0, v0, u1, v1 = host(u0), host(v0), host(u1), host(v1)
+    assert np.array_equal(u0.view(np.int64), u1.view(np.int64)) and np.array_equal(v0.view(np.int64), v1.view(np.int64))
+    with np.errstate(all="ignore"):
+        det = S[0] * S[1] - S[2] * S[2]
+        un = S[2] * S[4] - S[1] * S[3]
+        vn = S[3] * S[2] - S[0] * S[4]
+        uo = np.where(det != 0.0, un / det, 0.0)
+        vo = np.where(det != 0.0, vn / det, 0.0)
+    assert np.array_equal(u0, uo, equal_nan=True) and np.array_equal(v0, vo, equal_nan=True)
+    assert int((det == 0).sum()) > 0 and int(np.isinf(uo).sum()) > 0                           # the special classes really occur
+
+
+# ---------------------------------------------------------------------------- two pyramid levels in one pass
+@pytest.mark.parametrize("shape", [(1080, 1920), (448, 640), (160, 240), (8, 16), (12, 20), (16, 116), (16, 120), (16, 232), (16, 236),
+                                   (16, 240), (64, 472), (200, 468), (260, 936), (132, 64), (1080, 1080)])
+def test_pyrdown2_equals_two_passes_and_oracle(gpu_ctx, lkflow, oracle, torch, shape):
+    """pyrdown2_kernel (levels 1 and 2 of getGaussianPyramid, ParallelVideoPyr.cpp:566-575, from one pass over level 0) ==
+    two lkflow_pyrdown_f64_dev passes == the oracle's cv::pyrDown twice, bit for bit: widths around the 58-column wave period
+    (one / two columns left for the last wave, exactly full waves), strips of one and several blocks, the smallest shape."""
+    rng = np.random.default_rng(shape[0] * 31 + shape[1])
+    a = rng.random((3,) + shape)
+    a[1] = np.arange(shape[0] * shape[1], dtype=np.float64).reshape(shape) * 1e-3          # a ramp: exposes any mis-indexed tap
+    d = dev(torch, a)
+    l1, l2 = gpu_ctx.pyrdown2(d)
+    p1 = gpu_ctx.pyrdown(d)
+    p2 = gpu_ctx.pyrdown(p1)
+    assert torch.equal(l1, p1) and torch.equal(l2, p2)
+    for k in range(3):
+        o1 = oracle.pyr_down(a[k])
+        assert np.array_equal(host(l1[k]), o1) and np.array_equal(host(l2[k]), oracle.pyr_down(o1))
+    with pytest.raises(lkflow.LKFlowError):
+        gpu_ctx.pyrdown2(d[:, : shape[0] - 2])                         # rows not a multiple of 4
