@@ -191,6 +191,9 @@ def roofline_objects(lkf, name, cols, rows, levels, win, P, pairs_per_launch, lk
     }
     # the same fraction from the COMMITTED rocprofv3 kernel trace (profiles/*_kernel_trace_by_grid.csv via pmc_traffic.json): the
     # figure a reader can re-derive from profiles/ alone; null until tools/prof_round.sh has been re-run on this code
+    # the level-0 STAGE of SURVEY.md's model (warp + LK, "warp fused as gather") is this one launch when the level is fused; with a
+    # separate warp_kernel launch (small levels, LKFLOW_MUTATE_INPUTS) the LK launch is only part of it: null here (--profile-all has both)
+    roof["level0_stage_ms"] = round(lk0_avg_s * 1e3, 4) if fused else None
     rp = roof["rocprof_avg_launch_ms"]
     roof["frac_rocprof"] = round(lk0_bytes / (rp * 1e-3) / HBM_PEAK, 4) if rp else None
     path = {

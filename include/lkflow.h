@@ -158,7 +158,9 @@ int lkflow_lk_f64(lkflow_ctx *ctx, const double *img1, const double *img2, int r
  * both pair strides = S.  All pointers are DEVICE pointers on the context's GPU.  Work is
  * enqueued on `stream` (a hipStream_t, NULL = default stream); the call does not synchronise and, after
  * lkflow_ctx_reserve() for the shape, makes no allocation: it may be captured into a HIP graph and replayed
- * (tests/test_gpu_round3.py::test_graph_capture_after_reserve_replays_bitwise).
+ * (tests/test_gpu_round3.py::test_graph_capture_after_reserve_replays_bitwise).  One exception: while a host-buffer pair
+ * enqueued on this context (lkflow_enqueue_pair_*) has not been waited for, a call on another stream first synchronises with it
+ * on the host -- and is refused with LKFLOW_E_ARG if that stream is being captured: call lkflow_wait() before capturing.
  */
 int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next,
                                  size_t prev_pair_stride_bytes, size_t next_pair_stride_bytes,

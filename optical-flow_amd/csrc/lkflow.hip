@@ -699,17 +699,20 @@ int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int p
 
 // Levels 1 and 2 of a pyramid in one pass over level 0 (lk_kernels.h pyrdown2_kernel).  LK_NOT_TAKEN: shape not taken (the
 // caller runs two single-level passes): both levels must halve exactly and be big enough for the in-wave reflections.
+// Strip height: the kernel is latency-bound per wave (load -> filter -> DPP chain -> store), so MANY small workgroups beat tall
+// strips although a strip of 8 level-1 rows computes 11 (32 x 2 x 1080p: 0.302 ms at 8 rows, 0.319 at 16 and 64, 0.333 at 32;
+// two passes 0.335; profiles/r04_c_pyrdown2_ab.txt).  Small batches (the 240 x 160 stream: 0.054 against 0.055) keep two passes.
 #ifndef LK_PD2_TH
-#define LK_PD2_TH 64
+#define LK_PD2_TH 8
 #endif
-bool pyrdown2_applies(int H, int W)
+bool pyrdown2_applies(int H, int W, int planes)
 {
     static const int on = knob("LKFLOW_PD2", 1);              // A/B: 0 = two passes
-    return on && H % 4 == 0 && W % 4 == 0 && W / 2 >= 8 && H / 2 >= 4;
+    return on && H % 4 == 0 && W % 4 == 0 && W / 2 >= 8 && H / 2 >= 4 && (long long)(H / 2) * (W / 2) * planes >= (4ll << 20);
 }
 int launch_pyrdown2(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes d1, Planes d2, int planes, hipStream_t s)
 {
-    if (!pyrdown2_applies(H, W)) return LK_NOT_TAKEN;
+    if (H % 4 || W % 4 || W / 2 < 8 || H / 2 < 4) return LK_NOT_TAKEN;
     lk::PyrDown2Args a{};
     a.src = src; a.d1 = d1; a.d2 = d2; a.H = H; a.W = W;
     a.H1 = H / 2; a.W1 = W / 2; a.H2 = H / 4; a.W2 = W / 4;
@@ -984,6 +987,10 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
     // An enqueued host-buffer pair (lkflow_enqueue_pair_*) works in this context's arena on the context's own stream:
     // a call on any OTHER stream must not carve or overwrite the arena under it (lkflow.h: one pair per context in flight).
     if (ctx->host_inflight && s != ctx->own_stream) {
+        // (a host synchronisation is illegal while `s` is being captured into a graph: such a call is refused instead -- lkflow.h)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusNone) { ctx->last_error = "capture while an enqueued host pair is unwaited: lkflow_wait() first"; return LKFLOW_E_ARG; }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->own_stream));
         ctx->host_inflight = false;
     }
@@ -1027,7 +1034,7 @@ int lkflow_compute_batch_f64_dev(lkflow_ctx *ctx, double *prev, double *next, si
     // a2: Gaussian pyramids of both frames (built from the ORIGINAL images, before any warp).  Levels 1 and 2 come out of ONE
     // pass over level 0 where the shape allows (pyrdown2_kernel: level 1 is never read back)
     int l_first = 1;
-    if (L >= 3 && pyrdown2_applies(lv[0].H, lv[0].W)) {
+    if (L >= 3 && pyrdown2_applies(lv[0].H, lv[0].W, video ? P + 1 : 2 * P)) {
         ProfScope ps(ctx, LKFLOW_STAGE_PYRDOWN, 1, s);          // (levels 1 + 2: there is no separate level-2 record)
         int rc2 = LKFLOW_OK;
         if (video) rc2 = launch_pyrdown2(ctx, pyr(0, 0), lv[0].H, lv[0].W, pyr_w(1, 0), pyr_w(2, 0), P + 1, s);

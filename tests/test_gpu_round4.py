@@ -230,3 +230,31 @@ def test_pyrdown2_equals_two_passes_and_oracle(gpu_ctx, lkflow, oracle, torch, s
         assert np.array_equal(host(l1[k]), o1) and np.array_equal(host(l2[k]), oracle.pyr_down(o1))
     with pytest.raises(lkflow.LKFlowError):
         gpu_ctx.pyrdown2(d[:, : shape[0] - 2])                         # rows not a multiple of 4
+
+
+# ---------------------------------------------------------------------------- big windows: one association in every kernel form
+@pytest.mark.parametrize("win", [23, 25, 27, 29, 31])
+def test_big_windows_flat_half_and_forms_agree(lkflow, oracle, torch, win):
+    """Windows above 21 x 21 add the part two neighbouring windows share centre outwards in every form of lk_split_kernel
+    (accumulated as the DPP-shifted pair sums arrive at 23..27, from F's published pair sums at 29 / 31, fused warp): on a
+    half-flat image the flat half's flow is EXACTLY zero (additions only: no residue), the rest meets the oracle at 1e-9, and
+    the fused / unfused / per-pixel-reference forms agree (fused == unfused bit for bit)."""
+    import synth
+    a, b = synth.frame_pair(544, 960, seed=900 + win, shift=(1.4, -0.8))
+    a[:, :480] = 0.375; b[:, :480] = 0.375                       # flat left half
+    da, db = dev(torch, a)[None], dev(torch, b)[None]
+    with lkflow.Context(0) as ctx:
+        u, v = ctx.lk_batch(da, db, win)
+        ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, 0)
+        U0, V0 = ctx.compute_batch(da, db, 2, win)
+        ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, 1)
+        U1, V1 = ctx.compute_batch(da, db, 2, win)
+        torch.cuda.synchronize()
+    u, v = host(u)[0], host(v)[0]
+    r = win // 2
+    assert not u[:, : 480 - r - 2].any() and not v[:, : 480 - r - 2].any()      # windows wholly inside the flat half: det == 0 -> 0
+    uo, vo = oracle.lucas_kanade(a, b, win)
+    assert np.abs(u - uo).max() <= 1e-9 and np.abs(v - vo).max() <= 1e-9
+    assert torch.equal(U0, U1) and torch.equal(V0, V1)
+    Uo, Vo = oracle.coarse_to_fine(a, b, 2, win)
+    assert np.abs(host(U0)[0] - Uo).max() <= TOL and np.abs(host(V0)[0] - Vo).max() <= TOL
