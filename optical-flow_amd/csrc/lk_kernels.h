@@ -58,16 +58,19 @@ struct PyrDownArgs {
 
 constexpr int PD_WCOLS = 62;                          // valid output columns per wave
 
+// (bound_ctrl: a lane without a source -- lane 0 of a right shift, lane 63 of a left shift -- reads 0.  Rounds 1-3 passed a zero "old"
+// operand to update_dpp instead, which costs a v_mov_b32 0 in front of every DPP move: 28 of ~400 vector instructions per marched row of the
+// fused 3 x 3 kernel, whose vector pipes are 92 % busy.)
 __device__ __forceinline__ double dpp_wave_shr1(double v)      // lane l <- lane l-1
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double dpp_wave_shl1(double v)      // lane l <- lane l+1
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 
