@@ -64,6 +64,9 @@
 #ifndef LK_SPLIT_BOTH_MAX
 #define LK_SPLIT_BOTH_MAX 15   /* widest window whose S waves issue the LDS reads of both rows of a step up front */
 #endif
+#ifndef LK_SPLIT_FW_NOQDPP
+#define LK_SPLIT_FW_NOQDPP 0
+#endif
 #ifndef LK_SPLIT_QDPP
 #define LK_SPLIT_QDPP 1  /* S waves up to 21 x 21: neighbours' pair sums by DPP wave shifts instead of LDS reads (A/B: profiles/r03_c_*) */
 #endif
@@ -927,7 +930,8 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         constexpr int NQ = 2 * QH + 1;
         static_assert(K == 2 && HS <= PADJ, "pad lanes cover the taps");
         struct SRow { double q[NQ], sb, sa; };
-        constexpr bool STREAMED = LK_SPLIT_QDPP && !C::QSUM && WIN > 21;   // (see sload)
+        constexpr bool QDPP = LK_SPLIT_QDPP && !(FW && LK_SPLIT_FW_NOQDPP && WIN <= 21);   // (fused warp, A/B: pair sums by LDS reads again)
+        constexpr bool STREAMED = QDPP && !C::QSUM && WIN > 21;   // (see sload)
         double ring[WIN][K], pre[K];
 #pragma unroll
         for (int q = 0; q < WIN; ++q)
@@ -939,7 +943,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         auto sload = [&](auto spc, auto ec, SRow &r) __attribute__((always_inline)) {
             constexpr int SPP = decltype(spc)::value, E = decltype(ec)::value;   // LDS plane (step parity), row of the step
             const double *pp = &s_prod[SPP][E][f][2 * (PADJ + j)];
-            if constexpr (!C::QSUM && LK_SPLIT_QDPP) {
+            if constexpr (!C::QSUM && QDPP) {
                 // The lane reads ONLY its own pair and forms its pair sum; the neighbours' pair sums -- the same values, each
                 // formed once by the lane that owns the pair -- arrive by DPP wave shifts, one lane per shift.  Against NQ
                 // sixteen-byte LDS reads and NQ additions per row: 1 read, 1 addition and 2 (NQ - 1) 32-bit moves; the LDS pipe

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(64, 3) void lk_w3x1f_kernel(LKArgs a)
     const int y1 = min(y0 + a.th, H);
     const int ip = (int)a.i1.pitch;
     const bool col_in = xa >= 0 && xa < W;
+    const bool all_col_in = __builtin_amdgcn_ballot_w64(!col_in) == 0;
     const int xc = min(max(xa, 0), W - 1);
     const bool at_x0 = xa == 0;                              // left tap of column 0 = reflected column 1 = the right neighbour's pixel
     const double *I1 = a.i1.at(pair), *I2 = a.i2.at(pair);  // UN-warped level images (gathered)
@@ -61,8 +62,13 @@ __global__ __launch_bounds__(64, 3) void lk_w3x1f_kernel(LKArgs a)
         if (yw & 1) { uu = ((u1 + u2) * 4) * (1.0 / 64); vv = ((v1 + v2) * 4) * (1.0 / 64); }
         else { uu = (u0 + u1 * 6 + u2) * (1.0 / 64); vv = (v0 + v1 * 6 + v2) * (1.0 / 64); }
     };
+    // (only the first workgroup of a row holds image column 0, whose left tap is the reflected column 1: everywhere else the
+    // right shift and the select are skipped -- wave-uniform)
+    const bool has_x0 = blockIdx.x == 0;
     auto left_tap = [&](double c) __attribute__((always_inline)) {
-        const double l = dpp_wave_shr1(c), r = dpp_wave_shl1(c);
+        const double l = dpp_wave_shr1(c);
+        if (!has_x0) return l;
+        const double r = dpp_wave_shl1(c);
         return at_x0 ? r : l;
     };
     // gathers of one produced row in flight: coordinates + the two tap pairs of both images
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(64, 3) void lk_w3x1f_kernel(LKArgs a)
             double fx = f2d_x(lp1, p1, lc1, c1) + f2d_x(lp2, p2, lc2, c2);
             double fy = f2d_y(lp1, p1, lc1, c1) + f2d_y(lp2, p2, lc2, c2);
             const double ft = f2d_neg(lp1, p1, lc1, c1) + f2d_pos(lp2, p2, lc2, c2);
-            fx = keep ? fx : 0.0; fy = keep ? fy : 0.0;
+            if (!(row_in && all_col_in)) { fx = keep ? fx : 0.0; fy = keep ? fy : 0.0; }   // (wave-uniform test: rows / columns outside the image contribute 0)
             p[0] = fx * fx; p[1] = fy * fy; p[2] = fx * fy; p[3] = fx * ft; p[4] = fy * ft;
         }
         double S[5];
