@@ -59,7 +59,7 @@
 #define LK_SPLIT_PRIO_F 3
 #endif
 #ifndef LK_SPLIT_PRIO_W
-#define LK_SPLIT_PRIO_W 2
+#define LK_SPLIT_PRIO_W 0   /* (2 gained 3 % while the W waves waited for their gathers at the start of a step; with the gathers two steps ahead 0 is 3.5 % faster than 1 .. 3) */
 #endif
 #ifndef LK_SPLIT_BOTH_MAX
 #define LK_SPLIT_BOTH_MAX 15   /* widest window whose S waves issue the LDS reads of both rows of a step up front */
@@ -422,6 +422,10 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     [[maybe_unused]] auto up_srow_w = [&](int k) { const int Hc = H >> 1; return k < 0 ? min(1, Hc - 1) : (k > Hc - 1 ? Hc - 1 : k); };
     [[maybe_unused]] auto rot_row_off = [&](int t) { return max(up_srow_w(((ye0 + 2 * t) >> 1) + 1) - c_lo, 0); };   // row W-step t rotates in
 
+#ifdef LK_ABL_BARRIERS_ONLY   /* timing-only ablation: every wave only takes part in the pipeline's barriers */
+    for (int k = 0; k < NS + 1 + (FW ? 1 : 0); ++k) __syncthreads();
+    return;
+#endif
     if (FW && wv >= C::NB + 5 + C::NF) {
       if constexpr (FW) {                            // (not even compiled for the unfused kernel)
         // =========================================================================================
@@ -440,9 +444,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // taps that fall outside the image are zeroed afterwards (BORDER_CONSTANT 0) in a wave-uniform branch that holds no
         // memory instruction.
         const int widx = wv - (C::NB + 5 + C::NF);   // 0 .. NWW-1
-        // the W waves issue ahead of the S and B waves (they start the gathers the whole workgroup waits for two steps later;
-        // A/B on 32 x 1080p: level-0 launch 1.087 -> 1.053 ms)
-        __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_W);
+        if (LK_SPLIT_PRIO_W) __builtin_amdgcn_s_setprio(LK_SPLIT_PRIO_W);   // (A/B knob; see the definition)
         const int g = (widx & 1) * 64 + ((int)threadIdx.x & 63);   // block column g - 2: the two columns of F lane g >> 1
         const int Hc = H >> 1, Wc = W >> 1;
         const int xcol = min(max(x0 + 2 * ((g >> 1) - 1), 0), W - 2) + (g & 1);   // F's clamped column pair
@@ -479,7 +481,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             const float yf = (float)min(yy < 0 ? -yy : yy, H - 1);
             const float hx = (float)uu / 2, hy = (float)vv / 2;   // map build (ParallelVideoPyr.cpp:674-678), float32
 #ifdef LK_ABL_W_NOADDR   /* timing-only ablation: results wrong */
-            A.vo[0] = A.vo[1] = (int)(hx + hy + yf) & 0xFF8; A.wi[0] = A.wi[1] = 0; A.oob[0] = A.oob[1] = 0;
+            A.vo[0] = A.vo[1] = (int)(hx + hy + yf) & 0xFF8; A.wi[0] = A.wi[1] = 0; A.dx[0] = A.dx[1] = A.dy[0] = A.dy[1] = 0;
             if (0)
 #endif
 #pragma unroll
@@ -497,8 +499,11 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
                 A.dx[im] = ix - ixc; A.dy[im] = iy - iyc;
             }
         };
-        lk_d2 G[2][2];                               // gathers in flight: [image][tap row] = columns (ixc, ixc + 1)
-        auto wissue = [&](const WAddr &A) __attribute__((always_inline)) {
+        // gathers in flight: [image][tap row] = columns (ixc, ixc + 1); TWO sets, so that the gathers of step t + 1 are issued at the
+        // very start of step t while the blend of step t -- at its end -- still reads the other set: a gather has two pipeline steps
+        // to land (round-4 first form: half a step; HBM latency under load is longer than a step)
+        lk_d2 Ga[2][2], Gb[2][2];
+        auto wissue = [&](const WAddr &A, lk_d2 (&G)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int im = 0; im < 2; ++im) {
                 const __amdgpu_buffer_rsrc_t rI = im ? rI2 : rI1;
@@ -512,7 +517,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
                 G[im][0].x = g0x; G[im][0].y = g0y; G[im][1].x = g1x; G[im][1].y = g1y;
             }
         };
-        auto wblend = [&](auto pc, const WAddr &A) __attribute__((always_inline)) {     // blend the gathered taps of a step -> LDS plane
+        auto wblend = [&](auto pc, const WAddr &A, const lk_d2 (&G)[2][2]) __attribute__((always_inline)) {     // blend the gathered taps of a step -> LDS plane
             constexpr int WP = decltype(pc)::value;
 #pragma unroll
             for (int im = 0; im < 2; ++im) {
@@ -546,22 +551,25 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             for (int q = 0; q < 3; ++q) srow(up_srow_w(ib - 1 + q) - c_lo, hu[q], hv[q]);
             double nu, nv;
             srow(rot_row_off(0), nu, nv); waddr(0, nu, nv, cur);
-            wissue(cur);
+            wissue(cur, Ga);
             srow(rot_row_off(1), nu, nv); waddr(1, nu, nv, nxt);
         }
         __syncthreads();                             // F's service has published the row W-step 2 rotates in
-        // (the two address records swap roles from step to step: no copies)
-        auto wstep = [&](auto pc, int t, WAddr &now, WAddr &next) __attribute__((always_inline)) {
+        // step t: start the gathers of step t + 1, make the addresses of step t + 2, and only then blend step t's taps (gathered
+        // since the start of step t - 1) into the LDS plane F reads next step
+        auto wstep = [&](auto pc, int t, lk_d2 (&Gc)[2][2], lk_d2 (&Gn)[2][2]) __attribute__((always_inline)) {
             constexpr int WP = decltype(pc)::value;
-            wblend(pc, now);
-            wissue(next);
+            wissue(nxt, Gn);
             const double nu = s_c[WP ^ 1][0][g], nv = s_c[WP ^ 1][1][g];   // written by F in step t - 1: the row step t + 2 rotates in
-            waddr(t + 2, nu, nv, now);
+            WAddr nw;
+            waddr(t + 2, nu, nv, nw);
+            wblend(pc, cur, Gc);
+            cur = nxt; nxt = nw;
             __syncthreads();
         };
         for (int t = 0; t < NS; t += 2) {                               // NS is even
-            wstep(std::integral_constant<int, 0>{}, t, cur, nxt);
-            wstep(std::integral_constant<int, 1>{}, t + 1, nxt, cur);
+            wstep(std::integral_constant<int, 0>{}, t, Ga, Gb);
+            wstep(std::integral_constant<int, 1>{}, t + 1, Gb, Ga);
         }
         };
         if (widx < 2) wrole(std::integral_constant<int, 0>{});          // (wave-uniform)
@@ -840,14 +848,22 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
         // One step = the output row pair (y, y + 1), y = y0 + 2p even, at static pair position P2 = p mod TD (tap
         // slot; LDS step parity = (p + R) & 1).  Straight-line: every vector-memory instruction is issued
         // unconditionally (see the file header); the two solves are independent and interleave.
+#ifdef LK_ABL_B_NOSTORE   /* timing-only ablation: nothing is stored */
+        const int vo_lane = (int)0x80000000; (void)vxo;
+#else
         const int vo_lane = is_out ? vxo : (int)0x80000000;   // out of range: the store is dropped
+#endif
         auto solve5 = [&](const double (&S)[5], double &u, double &v) __attribute__((always_inline)) {
             const double det = S[0] * S[1] - S[2] * S[2];
             const double un = S[2] * S[4] - S[1] * S[3];
             const double vn = S[3] * S[2] - S[0] * S[4];
             const bool nz = det != 0.0;                     // cv::divide: x/0 -> 0
             double qu, qv;
+#ifdef LK_ABL_B   /* timing-only ablation: results wrong (kept finite and tiny so that the next level's gathers stay local) */
+            qu = un * 1e-300; qv = vn * 1e-300; (void)det;
+#else
             lk_div2(un, vn, det, qu, qv);                   // both quotients correctly rounded, one reciprocal iteration (lk_device.h)
+#endif
             u = nz ? qu : 0.0;
             v = nz ? qv : 0.0;
         };
@@ -863,7 +879,11 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             constexpr int SPB = (P2 + R) & 1;
             constexpr int TN = (P2 + TD - 1) % TD;          // the slot this pair's own taps just left
             const int y = y0 + 2 * p;
+#ifdef LK_ABL_B_NOLOAD   /* timing-only ablation: the coarse taps are not fetched (results wrong) */
+            if constexpr (false) {
+#else
             if constexpr (HAS_UP) {                         // taps consumed by the odd row of pair p + TD - 1
+#endif
                 int su, sv;
                 tap_off(y + 2 * (TD - 1) - 1, su, sv);
                 tp[TN][0] = buf_ld(rCU, us.jm, su); tp[TN][1] = buf_ld(rCU, us.jc, su); tp[TN][2] = buf_ld(rCU, us.jp, su);
@@ -1054,12 +1074,19 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             sload(SPc{}, E0{}, rA);
             if constexpr (BOTH) sload(SPc{}, E1{}, rB);
             __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
+#ifdef LK_ABL_S   /* timing-only ablation: results wrong */
+            SA[0] = rA.q[0] * 1e-300; SA[1] = rA.sb * 1e-300; SB[0] = rB.q[0] * 1e-300; SB[1] = rB.sa * 1e-300;
+            if (0)
+#endif
             ssum(std::integral_constant<int, Q>{}, rA, SA);
             if constexpr (!BOTH) {
                 __builtin_amdgcn_sched_barrier(0);
                 sload(SPc{}, E1{}, rB);
                 __builtin_amdgcn_s_waitcnt(0xC07F);
             }
+#ifdef LK_ABL_S
+            if (0)
+#endif
             ssum(std::integral_constant<int, (Q + 1) % WIN>{}, rB, SB);
             sstore(SPc{}, E0{}, SA);
             sstore(SPc{}, E1{}, SB);
