@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-end evidence: GPU suite, default bench line, rocprofv3 kernel traces + PMC passes for every config (-> gpurun_out/prof_<tag>)
-TAG=${1:-r04_d}
+TAG=${1:-r04_e}
 O=gpurun_out/final_$TAG; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -q -m gpu -x > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gpu_tests.log
 bash tools/prof_round.sh $TAG > $O/prof.log 2>&1; tail -3 $O/prof.log
