@@ -258,3 +258,37 @@ def test_big_windows_flat_half_and_forms_agree(lkflow, oracle, torch, win):
     assert torch.equal(U0, U1) and torch.equal(V0, V1)
     Uo, Vo = oracle.coarse_to_fine(a, b, 2, win)
     assert np.abs(host(U0)[0] - Uo).max() <= TOL and np.abs(host(V0)[0] - Vo).max() <= TOL
+
+
+# ---------------------------------------------------------------------------- the fused path under fuzz
+def test_fused_warp_fuzz_bitwise(lkflow, torch):
+    """60 random cases -- even shapes from 16 x 20 to 600 x 700, 2..4 levels, every window 5..31, 1..3 pairs, white noise (wild
+    coarse flows: taps far outside the image, saturated coordinates), flat halves, non-finite pixels in the coarse levels' inputs --
+    LKFLOW_OPT_FUSE_WARP 1 (every level that the kernel takes) against 0 (warp_kernel + LK): bit for bit, NaNs in the same places."""
+    rng = np.random.default_rng(77)
+    wins = list(range(5, 32, 2))
+    with lkflow.Context(0) as ctx:
+        for it in range(60):
+            levels = int(rng.integers(2, 5))
+            q = 1 << (levels - 1)
+            h = int(rng.integers(16 // q + 1, 600 // q)) * q
+            w = int(rng.integers(20 // q + 1, 700 // q)) * q
+            h += h & 1; w += w & 1
+            levels = min(levels, lkflow.getMaxLayer(w, h))
+            win = wins[int(rng.integers(0, len(wins)))]
+            P = int(rng.integers(1, 4))
+            a = rng.random((P, h, w)); b = rng.random((P, h, w))
+            if it % 3 == 0:
+                a[0, :, : w // 2] = 0.5; b[0, :, : w // 2] = 0.5
+            if it % 5 == 1:
+                a *= 1e6; b *= -1e6                                      # huge flows: short saturation of the tap coordinates
+            if it % 7 == 2:
+                a[0, h // 2, w // 2] = np.inf; b[-1, h // 3, w // 3] = np.nan
+            da, db = dev(torch, a), dev(torch, b)
+            ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, 0)
+            U0, V0 = ctx.compute_batch(da, db, levels, win)
+            ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, 1)
+            U1, V1 = ctx.compute_batch(da, db, levels, win)
+            torch.cuda.synchronize()
+            same = np.array_equal(host(U0), host(U1), equal_nan=True) and np.array_equal(host(V0), host(V1), equal_nan=True)
+            assert same, (it, h, w, levels, win, P)
