@@ -194,6 +194,10 @@ def roofline_objects(lkf, name, cols, rows, levels, win, P, pairs_per_launch, lk
     # the level-0 STAGE of SURVEY.md's model (warp + LK, "warp fused as gather") is this one launch when the level is fused; with a
     # separate warp_kernel launch (small levels, LKFLOW_MUTATE_INPUTS) the LK launch is only part of it: null here (--profile-all has both)
     roof["level0_stage_ms"] = round(lk0_avg_s * 1e3, 4) if fused else None
+    if fused and "lk_split" in kname:
+        roof["note"] = ("this launch is the WHOLE level-0 stage of SURVEY.md 8(d)'s model (36 B/px, 'warp fused as gather'): since round 4 the "
+                        "warp runs inside the LK kernel.  Rounds 1-3 priced the same 36 B/px against the LK launch alone (r03: 0.475-0.50); the "
+                        "r03 figure comparable to this frac is the stage, 36 B/px / (warp 0.549 + LK 0.628 ms) = 0.254")
     rp = roof["rocprof_avg_launch_ms"]
     roof["frac_rocprof"] = round(lk0_bytes / (rp * 1e-3) / HBM_PEAK, 4) if rp else None
     path = {
