@@ -39,16 +39,19 @@
 // computes and writes at the same time).  1-D grid, XCD-aware tile
 // order (column blocks of a strip and vertically adjacent strips share halo lines through one L2).
 //
-// FW = true (opt-in, LKFLOW_OPT_FUSE_WARP): two more "W" waves per block run the warp of the level (a9-a12: cv::pyrUp of
-// the coarse flow, float map, fixed-point remap of both UN-warped images) and hand the rows to F through LDS, so the warped
-// planes never reach memory; F then serves W the filtered coarse rows.  Bit-identical to warp_kernel + this kernel, but
-// slower on MI355X: a 10-wave block does not share a CU with a second one, so it is not the default.
+// FW = true (round 4: the default for tall levels, LKFLOW_OPT_FUSE_WARP): FOUR more "W" waves per block run the warp of the level
+// (a9-a12: cv::pyrUp of the coarse flow, float map, fixed-point remap of both UN-warped images; wave (half, e) makes row e of a
+// step's pair for 64 of the 128 columns) and hand the rows to F through LDS, so the warped planes never reach memory; F then has
+// no global loads of its own and serves W the horizontally filtered coarse rows.  12 waves = three per SIMD, <= 168 VGPRs, 89 KB
+// LDS: one workgroup per CU.  Gathers are issued two pipeline steps before their blend (two tap buffers), the four float weights
+// of a sample come from a 32 KB LDS table, frame pixels are made in trailing workgroups (lk_border_pixel<., true>).  Bit-identical
+// to warp_kernel + the unfused kernel; 0.94 ms against 0.52 + 0.56 per 32 x 1080p at 15 x 15 (DESIGN.md sections 4.3, 4.5; round 2's
+// two-wave form was slower than warp + LK: section 4.4).
 //
 // Only additions in the window sums (flat regions give exactly 0 like the reference); same products, solve and pyrUp
 // expressions as lk_march3.h.  Host-checked: W and H even, H > R + PF + 1, even strip height (a step's row pair is an
-// even and an odd output row); other shapes take lk_march3.h.  (The per-role cycle stamps and the timing-only ablation
-// builds of round 2 -- results wrong by design -- are gone from this header; they are in the git history, r02, and their
-// records under profiles/r02_*.)
+// even and an odd output row); other shapes take lk_march3.h.  The LK_ABL_* macros are timing-only ablations (results wrong by
+// design) behind the records in profiles/r04_a_fused_warp_ab.txt; no shipped build defines them.
 #pragma once
 #include "lk_w3x2.h"     // buf_ld2 (16-byte buffer loads), lk_march3.h
 
