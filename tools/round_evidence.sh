@@ -5,7 +5,7 @@ O=gpurun_out/final_$TAG; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -q -m gpu -x > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gpu_tests.log
 bash tools/prof_round.sh $TAG > $O/prof.log 2>&1; tail -3 $O/prof.log
 cp gpurun_out/prof_$TAG/pmc_traffic.json profiles/pmc_traffic.json
-/usr/bin/time -f "bench wall %e s" timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -1 $O/bench.err
+S0=$SECONDS; timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? wall $((SECONDS - S0)) s"
 python bench.py --steps 20 --profile-all --no-extras > $O/bench_stages.json 2>> $O/bench.err
 python - <<PY
 import json
