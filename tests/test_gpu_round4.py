@@ -292,3 +292,31 @@ def test_fused_warp_fuzz_bitwise(lkflow, torch):
             torch.cuda.synchronize()
             same = np.array_equal(host(U0), host(U1), equal_nan=True) and np.array_equal(host(V0), host(V1), equal_nan=True)
             assert same, (it, h, w, levels, win, P)
+
+
+# ---------------------------------------------------------------------------- the C-ABI frame-queue engine through ctypes
+def test_stream_engine_ctypes_matches_compute_video(gpu_ctx, lkflow, torch):
+    """lkflow_stream_* through the Python mirror: a 9-frame 8-bit stream over the device list [0, 0] == convertTo + compute_video +
+    flow_centroid on one context (centroid rows and two pairs' flows, bit for bit); more workers than pairs; the engine without
+    LKFLOW_STREAM_KEEP_FLOW refuses lkflow_stream_flow; a push of one frame is an argument error."""
+    import synth
+    base = synth.video(9, 96, 128, seed=21)
+    frames = np.clip(np.rint(base * 255.0), 0, 255).astype(np.uint8)
+    d = gpu_ctx.u8_to_f64(dev(torch, frames))
+    U, V = gpu_ctx.compute_video(d.reshape(9, 96, 128), 3, 7)
+    want = host(gpu_ctx.flow_centroid(U, V, 0.5))
+    for devices, keep in (([0, 0], True), ([0] * 12, False)):
+        with lkflow.StreamEngine(devices, 96, 128, 3, 7, keep_flow=keep) as eng:
+            eng.push(frames, thresh=0.5)
+            got = eng.centroids()
+            assert np.array_equal(got, want)
+            if keep:
+                for p in (0, 7):
+                    u, v = eng.flow(p)
+                    assert np.array_equal(u, host(U[p])) and np.array_equal(v, host(V[p]))
+            else:
+                with pytest.raises(lkflow.LKFlowError):
+                    eng.flow(0)
+            with pytest.raises(lkflow.LKFlowError):
+                eng.push(frames[:1])
+    assert want[:, 0].sum() > 100                              # the stream really moves
