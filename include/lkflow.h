@@ -65,6 +65,12 @@ const char *lkflow_version(void);
  * LKFLOW_OPT_LK_BATCH select other kernels); the shipped library has no other knob that could change it.  bench.py labels its
  * roofline with it. */
 int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok, int n_pairs, char *buf, size_t n);
+/* Diagnostics: how the wave-specialised LK kernel's launch partitions `column_strips` (column blocks x pairs) of `rows` rows
+ * over `slots` resident workgroups when a strip marches 2 * halo_rows + 6 rows more than it stores (lone_slots: see
+ * DESIGN.md section 4.1): out = {rows per strip of the first phase, column strips in the first phase, rows per strip of the
+ * second phase}; one height <=> out[1] == column_strips.  Pure host arithmetic (no GPU): tests/test_abi.py walks the
+ * workgroup -> tile map of such plans. */
+int lkflow_strip_plan(int rows, int halo_rows, long long column_strips, int slots, int lone_slots, long long out[3]);
 
 /* One context per GPU and caller thread: owns the device workspace (pyramids, per-level flow). */
 int lkflow_ctx_create(lkflow_ctx **out, int device);

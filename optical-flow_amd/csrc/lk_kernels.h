@@ -392,7 +392,30 @@ struct LKArgs {
     int gx, gy;       // lk_split: column blocks / row strips per pair (1-D grid, XCD-aware tile order)
     unsigned nmain;   // lk_split: marching workgroups; workgroups nmain .. gridDim.x - 1 do the frame pixels (0: separate launch)
     unsigned nbb;     // lk_split: frame workgroups per pair
+    // lk_split, two strip heights in one launch (split_tile below): workgroups 0 .. tilesA - 1 march the first csA column strips
+    // (a column strip = one column block of one pair) in gy strips of th rows, the others the remaining csB in gyB strips of thB
+    // rows.  One height: tilesA = nmain, csB = 0.
+    unsigned tilesA, csA, csB;
+    int gyB, thB;
 };
+
+// workgroup -> (pair, column block, first row, rows per strip) of the wave-specialised kernel: XCD-aware within each phase
+// (xcd_tile_id above; tilesA is a multiple of 8), column blocks fastest, then strips, then runs of gx column strips (= pairs,
+// when a phase starts on a pair)
+struct SplitTile { int pair, bx, y0, th; };
+__device__ __forceinline__ SplitTile split_tile(const LKArgs &a, unsigned blk, unsigned nmain)
+{
+    const bool pb = blk >= a.tilesA;
+    unsigned tile = pb ? xcd_tile_id(blk - a.tilesA, nmain - a.tilesA) : xcd_tile_id(blk, a.tilesA < nmain ? a.tilesA : nmain);
+    const unsigned gyp = (unsigned)(pb ? a.gyB : a.gy), np = pb ? a.csB : a.csA, c0 = pb ? a.csA : 0u, gx = (unsigned)a.gx;
+    const unsigned per = gx * gyp, run = tile / per, within = tile - run * per;
+    const unsigned left = np - run * gx, rs = left < gx ? left : gx;         // (the last run of a phase may be short)
+    const unsigned by = within / rs, cs = c0 + run * gx + (within - by * rs);
+    SplitTile t;
+    t.pair = (int)(cs / gx); t.bx = (int)(cs - (unsigned)t.pair * gx);
+    t.th = pb ? a.thB : a.th; t.y0 = (int)by * t.th;
+    return t;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Per-pixel LK (cross-check of the marching kernel on the GPU; reference summation order).

@@ -381,13 +381,11 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     // 1-D grid, XCD-aware tile order (lk_kernels.h): workgroups are dealt round-robin over the 8 XCDs (private L2s), so
     // with the natural order the column blocks of one strip -- which share 2 HL halo columns -- and vertically adjacent
     // strips -- which share 2R apron rows -- land on different L2s and every shared line is fetched from HBM once per XCD
-    unsigned tile = xcd_tile_id(blockIdx.x, a.nmain ? a.nmain : gridDim.x);
-    const int bx = tile % a.gx; tile /= a.gx;
-    const int by = tile % a.gy;
-    const int pair = tile / a.gy;
+    const SplitTile st = split_tile(a, blockIdx.x, a.nmain ? a.nmain : gridDim.x);
+    const int bx = st.bx, pair = st.pair;
     const int H = a.H, W = a.W;
-    const int y0 = by * a.th;                        // even (host)
-    const int y1 = min(y0 + a.th, H);
+    const int y0 = st.y0;                            // even (host)
+    const int y1 = min(y0 + st.th, H);
     const int nrows = y1 - y0;                       // even (H is even or the strip height is: host)
     const int nm = nrows + 2 * R;                    // marched product rows: image rows y0-R .. y1-1+R
     const int yy0 = y0 - R;

@@ -256,7 +256,7 @@ int blocks_per_cu(lkflow_ctx *ctx, Kern kern, int threads)
 // of a pair (one workgroup per CU = +25 % time for the same work).  Measured on 32 x 1080p, 15 x 15
 // (tools/sweep_lk_th2.py, profiles/r02_i_lk_strip_height_repeat.txt): 4.5 rounds of 270-row strips 0.645 ms against
 // 0.671 ms for the 9 whole rounds of 136-row strips that the whole-rounds rule picks.
-inline int pick_tile_rows(int H, int R, long long blocks_per_strip, long long slots, long long lone_cus = 0)
+inline int pick_tile_rows(int H, int R, long long blocks_per_strip, long long slots, long long lone_cus = 0, long long *cost_out = nullptr)
 {
     long long best = -1;
     int th = H;
@@ -270,7 +270,55 @@ inline int pick_tile_rows(int H, int R, long long blocks_per_strip, long long sl
         const long long cost = rounds100 * (t + 2 * R + 6);
         if (best < 0 || cost < best) { best = cost; th = t; }
     }
+    if (cost_out) *cost_out = best;
     return th;
+}
+
+// Two strip heights in one launch (the wave-specialised kernel's 1-D grid; lk_kernels.h split_tile).  Workgroups are dispatched
+// in grid order into the slots earlier ones free, so a launch runs in rounds, and with ONE height the last round is either
+// partly empty or paid for with short strips everywhere (each strip marches 2R + ~6 rows more than it stores: 32 x 1080p at
+// 15 x 15 fused = 576 column strips on 256 slots -> 9 rounds of 270-row strips = 2646 marched rows per slot against 2430 stored).
+// Plan: the first csA column strips in tall strips that fill k whole rounds exactly, the remaining nblk - csA in short strips
+// that fill the last round(s) (2 x 1104 + 294 = 2502).  Same cost model as pick_tile_rows; one height when that is cheaper,
+// when the user fixed the strip height, or when a tall strip would exceed `cap` rows.  Results do not depend on the partition
+// (tests/test_gpu_round2.py test_every_window_multi_strip_multi_block).
+struct StripPlan { int thA; long long csA; int thB; };
+inline StripPlan pick_strip_plan(int H, int R, long long nblk, long long slots, long long lone_cus, long long cap)
+{
+    static const int two = knob("LKFLOW_TWO_HEIGHTS", 1);
+    long long best = 0;
+    int th = pick_tile_rows(H, R, nblk, slots, lone_cus, &best);
+    th = (th + 1) & ~1;
+    StripPlan p{th, nblk, th};
+    if (!two || (slots & 7)) return p;
+    for (int gyA = 1; gyA <= 8; ++gyA) {
+        const int tA = ((H + gyA - 1) / gyA + 1) & ~1;
+        if ((H + tA - 1) / tA != gyA || tA > cap) continue;
+        for (long long k = 1; k * slots / gyA < nblk; ++k) {
+            if ((k * slots) % gyA) continue;
+            const long long csA = k * slots / gyA;
+            long long cB = 0;
+            const int tB = (pick_tile_rows(H, R, nblk - csA, slots, lone_cus, &cB) + 1) & ~1;
+            if (tB >= tA) continue;
+            const long long cost = k * 100 * (tA + 2 * R + 6) + cB;
+            if (cost < best) { best = cost; p = StripPlan{tA, csA, tB}; }
+        }
+    }
+    return p;
+}
+
+// fills the tile fields of the wave-specialised kernel's arguments from a plan; returns the number of marching workgroups
+// (0: too many for a 32-bit grid)
+inline unsigned apply_strip_plan(lk::LKArgs &a, const StripPlan &p, int gx, long long nblk)
+{
+    a.gx = gx;
+    a.th = p.thA; a.gy = (a.H + p.thA - 1) / p.thA;
+    a.thB = p.thB; a.gyB = (a.H + p.thB - 1) / p.thB;
+    const long long tA = p.csA * a.gy, tB = (nblk - p.csA) * a.gyB;
+    if (tA + tB > 0x7fffffffLL) return 0;
+    a.csA = (unsigned)p.csA; a.csB = (unsigned)(nblk - p.csA);
+    a.tilesA = (unsigned)tA;
+    return (unsigned)(tA + tB);
 }
 
 template <int WIN, int TX>
@@ -346,23 +394,23 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
     using C = lk::SplitCfg<WIN, K>;
     if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return LK_NOT_TAKEN;   // odd / tiny levels: one-role kernel
     const int gx = (a.W + C::XO - 1) / C::XO;
-    int th = ctx->tile_rows;
-    if (th <= 0) {
+    const long long pmax = std::max(a.i1.pitch, std::max(a.u.pitch, a.v.pitch));
+    const long long cap = (0x7fffffffLL / (pmax * 8) - 2 * C::R - 8) & ~1LL;   // (32-bit byte offsets from a strip's first row)
+    if (cap < 2) return LKFLOW_E_ARG;
+    const long long nblk = (long long)gx * pairs;
+    StripPlan plan;
+    if (ctx->tile_rows > 0) {
+        const int th = (int)std::min<long long>((ctx->tile_rows + 1) & ~1, cap);   // even strips: row parity is static in the unrolled pipeline
+        plan = StripPlan{th, nblk, th};
+    } else {
         const int bpc = has_up ? blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, true>, C::NT)
                                : blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, false>, C::NT);
-        th = pick_tile_rows(a.H, C::R + 1, (long long)gx * pairs, (long long)ctx->n_cu * bpc, bpc == 2 ? ctx->n_cu : 0);
+        plan = pick_strip_plan(a.H, C::R + 1, nblk, (long long)ctx->n_cu * bpc, bpc == 2 ? ctx->n_cu : 0, cap);
+        if (plan.thA > cap) plan = StripPlan{(int)cap, nblk, (int)cap};
     }
-    th = (th + 1) & ~1;                              // even strips: row parity is static in the unrolled pipeline
-    {
-        const long long pmax = std::max(a.i1.pitch, std::max(a.u.pitch, a.v.pitch));
-        const long long cap = (0x7fffffffLL / (pmax * 8) - 2 * C::R - 8) & ~1LL;
-        if (cap < 2) return LKFLOW_E_ARG;
-        if (th > cap) th = (int)cap;
-    }
-    a.th = th;
-    a.gx = gx; a.gy = (a.H + th - 1) / th;
-    if ((long long)a.gx * a.gy * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
-    dim3 grid((unsigned)(a.gx * a.gy * pairs));      // 1-D: the kernel orders the tiles per XCD
+    const unsigned nmarch = apply_strip_plan(a, plan, gx, nblk);
+    if (!nmarch) return LKFLOW_E_ARG;
+    dim3 grid(nmarch);                               // 1-D: the kernel orders the tiles per XCD
     // the frame of clipped-window pixels (SerialPyr.cpp:94-95) and the outermost ring: frame pixels per pair
     const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
     const long long nfp = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
@@ -401,28 +449,28 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s, i
     // (forms row * pitch with a 24-bit multiply and clamps unsaturated tap coordinates: see the W role)
     if (a.i1.pitch != a.i2.pitch || (long long)a.H * a.i1.pitch * 8 > 0x7fffffffLL || a.i1.pitch * 8 >= (1 << 24) || a.H > 32766 || a.W > 32766) return LK_NOT_TAKEN;
     const int gx = (a.W + C::XO - 1) / C::XO;
-    int th = ctx->tile_rows;
-    if (th <= 0) {
+    const long long pmax = std::max(a.u.pitch, a.v.pitch);
+    const long long cap = (0x7fffffffLL / (pmax * 8) - 2 * C::R - 8) & ~1LL;
+    if (cap < 2) return LKFLOW_E_ARG;
+    const long long nblk = (long long)gx * pairs;
+    StripPlan plan;
+    if (ctx->tile_rows > 0) {
+        const int th = (int)std::min<long long>((ctx->tile_rows + 1) & ~1, cap);
+        plan = StripPlan{th, nblk, th};
+    } else {
         const int bpc = blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, true, true>, C::NT);
-        th = pick_tile_rows(a.H, C::R + 2, (long long)gx * pairs, (long long)ctx->n_cu * bpc);
+        plan = pick_strip_plan(a.H, C::R + 2, nblk, (long long)ctx->n_cu * bpc, 0, cap);
+        if (plan.thA > cap) plan = StripPlan{(int)cap, nblk, (int)cap};
     }
-    th = (th + 1) & ~1;
-    {
-        const long long pmax = std::max(a.u.pitch, a.v.pitch);
-        const long long cap = (0x7fffffffLL / (pmax * 8) - 2 * C::R - 8) & ~1LL;
-        if (cap < 2) return LKFLOW_E_ARG;
-        if (th > cap) th = (int)cap;
-    }
-    a.th = th;
-    a.gx = gx; a.gy = (a.H + th - 1) / th;
-    if ((long long)a.gx * a.gy * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
+    const unsigned nmarch = apply_strip_plan(a, plan, gx, nblk);
+    if (!nmarch) return LKFLOW_E_ARG;
     // the frame of clipped-window pixels and the outermost ring (its warped taps are made on the fly, lk_border_pixel<., true>):
     // trailing workgroups of the same launch, as in the unfused kernel
     const long long nr = std::min(2 * C::R, a.H), nc = std::min(2 * C::R, a.W);
     const long long nfp = nr * a.W + (a.H > 2 * C::R ? (long long)(a.H - 2 * C::R) * nc : 0);
     if (nfp + 2 * C::NT >= 0x7fffffffLL) return LKFLOW_E_ARG;
     const long long nbb = (nfp + C::NT - 1) / C::NT;
-    dim3 grid((unsigned)(a.gx * a.gy * pairs));
+    dim3 grid(nmarch);
     if ((long long)grid.x + nbb * pairs > 0x7fffffffLL) return LKFLOW_E_ARG;
     a.nmain = grid.x; a.nbb = (unsigned)nbb;
     static const int no_border = knob("LKFLOW_ABL_NO_BORDER", 0);   // (timing-only ablation of a debug-knob build: results wrong)
@@ -474,10 +522,14 @@ bool fused_split_applies(const lkflow_ctx *ctx, int win, int W, int H, int pairs
     const int mode = env >= 0 ? env : ctx->fuse_warp;
     if (!mode || ctx->impl != 0 || win > LKFLOW_SPLIT_FUSED_MAX_WIN || !split_applies(win, W, H)) return false;
     if (mode == 1) return true;
-    (void)pairs;                                                 // (1, 4 and 32 pairs of 1080p all gain: the rule is the level's height)
-    // 29 x 29 and 31 x 31 run one workgroup per CU unfused as well: fused wins from 256 rows on; up to 15 x 15 a 540-row level is a
-    // wash (0.308 fused against 0.299 for 32 x 960 x 540), 1080 rows gain 7 %
-    return H >= (win >= 29 ? 256 : (win >= 17 ? 512 : 768));
+    // Fused wins from 256 rows on at every window since the launch plan has two strip heights (pick_strip_plan: one workgroup per
+    // CU made the fused kernel's last round expensive -- 32 x 960 x 540 at 15 x 15 was a wash, 0.308 fused against 0.299, and is
+    // 0.258 against 0.307 now; 270-row levels: 0.071 against 0.088 at 5 x 5, 0.041 against 0.049 at 21 x 21); 160- and 80-row
+    // levels lose when the launch fills the GPU (240 x 160 x 244 stream: 0.26 against 0.22, 0.117 against 0.083; 240 x 136 x 64:
+    // 0.080 against 0.067) and win when it does not -- a launch of a few dozen workgroups is bound by its own latency, and one
+    // launch beats two (16 x 320 x 224 at 7 x 7: 0.036 against 0.045; 160 x 112: 0.026 against 0.029; 80 x 56: 0.015 against
+    // 0.027).  profiles/r04_g_two_heights_ab.txt
+    return H >= 256 || (long long)pairs * W * H <= 1310720;
 }
 
 // LK_NOT_TAKEN: this window has no wave-specialised instantiation
@@ -804,6 +856,14 @@ int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok,
     else {
         snprintf(buf, n, "lk::lk_march3_kernel<%d, %d, %s>", win, lk3_block_width(win), up);
     }
+    return LKFLOW_OK;
+}
+
+int lkflow_strip_plan(int rows, int halo_rows, long long column_strips, int slots, int lone_slots, long long out[3])
+{
+    if (!out || rows < 2 || (rows & 1) || halo_rows < 0 || column_strips < 1 || slots < 1 || lone_slots < 0) return LKFLOW_E_ARG;
+    const StripPlan p = pick_strip_plan(rows, halo_rows, column_strips, slots, lone_slots, 0x7fffffff);
+    out[0] = p.thA; out[1] = p.csA; out[2] = p.thB;
     return LKFLOW_OK;
 }
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "lkflow_last_error": (ctypes.c_char_p, [_vp]),
     "lkflow_version": (ctypes.c_char_p, []),
     "lkflow_lk_kernel_name": (_i, [_i, _i, _i, _i, _i, _i, ctypes.c_char_p, ctypes.c_size_t]),
+    "lkflow_strip_plan": (_i, [_i, _i, ctypes.c_longlong, _i, _i, ctypes.POINTER(ctypes.c_longlong)]),
     "lkflow_ctx_create": (_i, [ctypes.POINTER(_vp), _i]),
     "lkflow_ctx_destroy": (None, [_vp]),
     "lkflow_ctx_reserve": (_i, [_vp, _i, _i, _i, _i]),
@@ -141,6 +142,15 @@ def lk_kernel_name(rows, cols, win, has_up=True, fused_ok=True, pairs=1):
     if rc != 0:
         raise LKFlowError(rc)
     return buf.value.decode()
+
+
+def strip_plan(rows, halo_rows, column_strips, slots, lone_slots=0):
+    """(rows per strip of phase A, column strips in phase A, rows per strip of phase B) of the wave-specialised LK launch."""
+    out = (ctypes.c_longlong * 3)()
+    rc = lib().lkflow_strip_plan(int(rows), int(halo_rows), int(column_strips), int(slots), int(lone_slots), out)
+    if rc != 0:
+        raise LKFlowError(rc)
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def getMaxLayer(img_or_cols, rows=None):

@@ -107,3 +107,68 @@ def test_library_carries_the_digest_of_its_sources(lkflow):
     assert "src:" in v
     if not os.environ.get("LKFLOW_LIB"):
         assert v.rsplit("src:", 1)[1] == ge.lib_digest() == ge.csrc_digest(), "liblkflow.so is stale: python __graft_entry__.py build"
+
+
+def _xcd_tile_id(lin, n):
+    xcd, q, r = lin & 7, n >> 3, n & 7
+    return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + (lin >> 3)
+
+
+def _split_tile(blk, nmain, gx, gyA, thA, tilesA, csA, csB, gyB, thB):
+    """lk_kernels.h split_tile, restated: workgroup -> (pair, column block, first row, strip height)."""
+    pb = blk >= tilesA
+    tile = _xcd_tile_id(blk - tilesA, nmain - tilesA) if pb else _xcd_tile_id(blk, min(tilesA, nmain))
+    gyp, npp, c0 = (gyB, csB, csA) if pb else (gyA, csA, 0)
+    per = gx * gyp
+    run, within = divmod(tile, per)
+    rs = min(npp - run * gx, gx)
+    by, k = divmod(within, rs)
+    cs = c0 + run * gx + k
+    th = thB if pb else thA
+    return cs // gx, cs % gx, by * th, th
+
+
+@pytest.mark.parametrize("rows,halo,gx,pairs,slots,lone", [
+    (1080, 9, 18, 32, 256, 0),      # headline level 0, fused: 2 rounds of whole columns + 1 round of quarter strips
+    (540, 8, 9, 32, 512, 256),      # headline level 1, two workgroups per CU
+    (270, 8, 5, 32, 512, 256),
+    (2160, 12, 37, 8, 256, 0),      # 4K level 0
+    (4320, 17, 82, 32, 256, 0),     # 8K level 0
+    (160, 8, 3, 244, 512, 256),     # 240 x 160 stream
+    (64, 4, 1, 1, 512, 256), (96, 8, 2, 3, 304, 0), (1080, 9, 18, 1, 256, 0), (1080, 3, 10, 48, 256, 0), (2, 1, 1, 1, 256, 0),
+])
+def test_strip_plan_covers_every_tile_once(lkflow, rows, halo, gx, pairs, slots, lone):
+    """The launch plan of the wave-specialised LK kernel (two strip heights in one launch): the planner's output walked
+    through the kernel's workgroup -> tile map covers every (pair, column block, row) exactly once, phase A fills whole rounds,
+    and the plan never costs more than one height under the planner's own model."""
+    nblk = gx * pairs
+    thA, csA, thB = lkflow.strip_plan(rows, halo, nblk, slots, lone)
+    assert thA % 2 == 0 and thB % 2 == 0 and 1 <= csA <= nblk and thB <= thA
+    gyA, gyB = -(-rows // thA), -(-rows // thB)
+    tilesA, csB = csA * gyA, nblk - csA
+    if csB:
+        assert thB < thA and tilesA % slots == 0 and tilesA % 8 == 0
+    nmain = tilesA + csB * gyB
+    seen = {}
+    for blk in range(nmain):
+        pair, bx, y0, th = _split_tile(blk, nmain, gx, gyA, thA, tilesA, csA, csB, gyB, thB)
+        assert 0 <= pair < pairs and 0 <= bx < gx and 0 <= y0 < rows and y0 % 2 == 0
+        for y in range(y0, min(y0 + th, rows), 2):
+            key = (pair, bx, y)
+            assert key not in seen, (blk, seen[key], key)
+            seen[key] = blk
+    assert len(seen) == nblk * (rows // 2)
+
+    def cost(n, th):                                   # pick_tile_rows' model: rounds x marched rows
+        full, rem = divmod(n * -(-rows // th), slots)
+        return (full * 100 + (0 if rem == 0 else (62 if rem <= lone else 100))) * (th + 2 * halo + 6)
+    two = cost(csA, thA) + (cost(csB, thB) if csB else 0)
+    uniform = min(cost(nblk, t) for t in range(min(6, rows), rows + 1, 2))   # (the planner does not try strips under 6 rows)
+    assert two <= uniform * 1.02 + 200, (two, uniform)   # (the planner's uniform candidate list is a subset: rounding slack)
+
+
+def test_strip_plan_headline_shape(lkflow):
+    """32 x 1080p, 15 x 15, fused level 0: 576 column strips on 256 one-workgroup CUs -> 512 whole columns + 64 in quarters."""
+    assert lkflow.strip_plan(1080, 9, 576, 256, 0) == (1080, 512, 270)
+    with pytest.raises(lkflow.LKFlowError):
+        lkflow.strip_plan(1081, 9, 576, 256, 0)

@@ -294,6 +294,35 @@ def test_fused_warp_fuzz_bitwise(lkflow, torch):
             assert same, (it, h, w, levels, win, P)
 
 
+# ---------------------------------------------------------------------------- two strip heights in one launch
+@pytest.mark.parametrize("P,h,w,levels,win,fuse", [
+    (32, 1080, 1920, 3, 15, 2),    # headline: 576 column strips on 256 CUs -> 512 whole columns + 64 in quarters (fused level 0),
+                                   #           level 1 fused: 256 whole + 32 in eighths; phase B starts inside a pair, short last run
+    (244, 160, 240, 3, 15, 2),     # the 240 x 160 stream shape, unfused, two workgroups per CU: 512 whole + 220 in halves
+    (40, 544, 960, 2, 21, 0),      # unfused 21 x 21 and its warp-less coarsest level
+    (24, 512, 2176, 2, 31, 1),     # 31 x 31 fused (one workgroup per CU unfused too)
+])
+def test_two_strip_heights_do_not_change_a_bit(lkflow, torch, P, h, w, levels, win, fuse):
+    """Launches big enough for the two-height plan (lkflow.hip pick_strip_plan; tests/test_abi.py walks the tile map on the CPU)
+    against the same call with ONE forced strip height (LKFLOW_OPT_TILE_ROWS): every pair bit for bit, no pixel left unwritten
+    (the outputs start as NaN)."""
+    rng = np.random.default_rng(4000 + win)
+    base = rng.random((h + 64, w + 64))
+    a = np.stack([base[(3 * k) % 50:(3 * k) % 50 + h, (5 * k) % 60:(5 * k) % 60 + w] for k in range(P)])
+    b = np.stack([base[(3 * k) % 50 + 1:(3 * k) % 50 + 1 + h, (5 * k) % 60 + 2:(5 * k) % 60 + 2 + w] for k in range(P)])
+    da, db = dev(torch, a), dev(torch, b)
+    with lkflow.Context(0) as ctx:
+        ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, fuse)
+        U = torch.full_like(da, float("nan")); V = torch.full_like(da, float("nan"))
+        ctx.compute_batch(da, db, levels, win, out=(U, V))
+        ctx.set_option(lkflow.LKFLOW_OPT_TILE_ROWS, 46)
+        U1 = torch.full_like(da, float("nan")); V1 = torch.full_like(da, float("nan"))
+        ctx.compute_batch(da, db, levels, win, out=(U1, V1))
+        torch.cuda.synchronize()
+    assert not torch.isnan(U).any() and not torch.isnan(V).any()
+    assert torch.equal(U, U1) and torch.equal(V, V1)
+
+
 # ---------------------------------------------------------------------------- the C-ABI frame-queue engine through ctypes
 def test_stream_engine_ctypes_matches_compute_video(gpu_ctx, lkflow, torch):
     """lkflow_stream_* through the Python mirror: a 9-frame 8-bit stream over the device list [0, 0] == convertTo + compute_video +
