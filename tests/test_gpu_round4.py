@@ -323,6 +323,35 @@ def test_two_strip_heights_do_not_change_a_bit(lkflow, torch, P, h, w, levels, w
     assert torch.equal(U, U1) and torch.equal(V, V1)
 
 
+def test_two_strip_heights_fuzz_many_small_pairs(lkflow, torch):
+    """24 random launches of MANY small pairs (150..700 pairs of 24..140 rows x 60..420 columns, 2 levels, windows 5..31): the
+    column strips outnumber the resident workgroups, so the plan has two phases, phase B starts inside a pair and ends in a
+    short run -- against one forced strip height, with the warp fused and not: bit for bit, every pixel written."""
+    rng = np.random.default_rng(4242)
+    wins = list(range(5, 32, 2))
+    for it in range(24):
+        win = wins[int(rng.integers(0, len(wins)))]
+        h = int(rng.integers(max(12, win // 2 + 4), 70)) * 2
+        w = int(rng.integers(30, 210)) * 2
+        P = int(rng.integers(150, 700))
+        base = rng.random((h + 40, w + 40))
+        k = np.arange(P)
+        oy, ox = (7 * k) % 37, (11 * k) % 39
+        a = np.stack([base[y:y + h, x:x + w] for y, x in zip(oy, ox)])
+        b = np.stack([base[y + 1:y + 1 + h, x + 1:x + 1 + w] for y, x in zip(oy, ox)])
+        da, db = dev(torch, a), dev(torch, b)
+        with lkflow.Context(0) as ctx:
+            ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, it & 1)
+            U = torch.full_like(da, float("nan")); V = torch.full_like(da, float("nan"))
+            ctx.compute_batch(da, db, 2, win, out=(U, V))
+            ctx.set_option(lkflow.LKFLOW_OPT_TILE_ROWS, int(rng.integers(3, 40)) * 2)
+            U1 = torch.full_like(da, float("nan")); V1 = torch.full_like(da, float("nan"))
+            ctx.compute_batch(da, db, 2, win, out=(U1, V1))
+            torch.cuda.synchronize()
+        assert not torch.isnan(U).any() and not torch.isnan(V).any(), (it, h, w, win, P)
+        assert torch.equal(U, U1) and torch.equal(V, V1), (it, h, w, win, P)
+
+
 # ---------------------------------------------------------------------------- the C-ABI frame-queue engine through ctypes
 def test_stream_engine_ctypes_matches_compute_video(gpu_ctx, lkflow, torch):
     """lkflow_stream_* through the Python mirror: a 9-frame 8-bit stream over the device list [0, 0] == convertTo + compute_video +
