@@ -89,12 +89,12 @@ int lkflow_ctx_reserve(lkflow_ctx *ctx, int rows, int cols, int pyr_levels, int 
                                   points move data by asynchronous DMA instead of the pageable path.  ONLY for buffers that
                                   outlive the context or are re-used call after call (a video loop's Mats): a registered
                                   buffer must not be freed while the option is on. */
-#define LKFLOW_OPT_FUSE_WARP 5 /* windows 5..21 on even levels: the warp of a level runs INSIDE its LK kernel (four "W" waves of the
+#define LKFLOW_OPT_FUSE_WARP 5 /* windows 5..31 on even levels: the warp of a level runs INSIDE its LK kernel (four "W" waves of the
                                   wave-specialised kernel make the warped rows and hand them over through LDS), so the warped planes
                                   never reach memory; bit-identical to warp + LK.  0 = never, 1 = wherever the kernel takes the
-                                  shape, 2 (default) = where it was measured faster (levels of >= 256 rows with enough column
-                                  blocks to give every CU a tall strip: DESIGN.md section 4).  Never at level 0 of a
-                                  LKFLOW_MUTATE_INPUTS call (the caller wants the warped images). */
+                                  shape, 2 (default) = where it was measured faster: levels of >= 256 rows, and any level of a
+                                  launch of at most 1.25 Mi pixels (pairs x rows x cols).  Never at level 0
+                                  of a LKFLOW_MUTATE_INPUTS call (the caller wants the warped images). */
 #define LKFLOW_OPT_LK_BATCH 6  /* 0 (default) / 1: windows 5..15 on even levels run the batch-synchronous LK kernel (lk_batch.h:
                                   8-wave workgroups, 8 rows per barrier pair, 5 window-sum waves next to 3 producer waves)
                                   instead of the wave-specialised one.  Same expressions; the vertical window sums are

@@ -739,8 +739,12 @@ int launch_pyrdown(lkflow_ctx *ctx, CPlanes src, int H, int W, Planes dst, int p
 #define LK_PD_TH 16
 #endif
     a.th = LK_PD_TH;
+    a.gx = (a.Wd + 4 * lk::PD_WCOLS - 1) / (4 * lk::PD_WCOLS);
+    // a launch that does not fill the GPU is as long as ONE workgroup's march (one 1080p pair: 272 workgroups of 16 rows 0.020 ms,
+    // 1088 of 4 rows 0.013; profiles/r04_g_two_heights_ab.txt E): shorter strips until there are four workgroups per CU
+    while (a.th > 4 && (long long)a.gx * ((a.Hd + a.th - 1) / a.th) * planes < 4LL * ctx->n_cu) a.th /= 2;
     { static const int e = knob("LKFLOW_PD_TH", 0); if (e > 0) a.th = e; }
-    a.gx = (a.Wd + 4 * lk::PD_WCOLS - 1) / (4 * lk::PD_WCOLS); a.gy = (a.Hd + a.th - 1) / a.th;
+    a.gy = (a.Hd + a.th - 1) / a.th;
     if ((long long)(2 * a.th + 6) * 8 * std::max(src.pitch, dst.pitch) > 0x7fffffffLL) return LKFLOW_E_ARG;   // strip-relative 32-bit offsets
     const long long n = (long long)a.gx * a.gy * planes;
     if (n > 0x7fffffffLL) return LKFLOW_E_ARG;
