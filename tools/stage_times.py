@@ -11,6 +11,8 @@ prev, nxt = synth.frame_pairs_torch(P, H, W, "cuda", seed=1234)
 ctx = lk.Context(0)
 fuse = os.environ.get("FUSE")
 if fuse is not None: ctx.set_option(lk.LKFLOW_OPT_FUSE_WARP, int(fuse))
+tile = os.environ.get("TILE")
+if tile is not None: ctx.set_option(lk.LKFLOW_OPT_TILE_ROWS, int(tile))
 U = torch.empty_like(prev); V = torch.empty_like(prev)
 for _ in range(40): ctx.compute_batch(prev, nxt, L, win, out=(U, V))
 torch.cuda.synchronize()
