@@ -49,8 +49,8 @@
 // two-wave form was slower than warp + LK: section 4.4).
 //
 // Only additions in the window sums (flat regions give exactly 0 like the reference); same products, solve and pyrUp
-// expressions as lk_march3.h.  Host-checked: W and H even, H > R + PF + 1, even strip height (a step's row pair is an
-// even and an odd output row); other shapes take lk_march3.h.  The LK_ABL_* macros are timing-only ablations (results wrong by
+// expressions as lk_march3.h.  Host-checked: W even, H even below a coarser level (a coarsest level may be odd: see nrows),
+// H > R + PF + 1, even strip height (a step's row pair is an even and an odd output row); other shapes take lk_march3.h.  The LK_ABL_* macros are timing-only ablations (results wrong by
 // design) behind the records in profiles/r04_a_fused_warp_ab.txt; no shipped build defines them.
 #pragma once
 #include "lk_w3x2.h"     // buf_ld2 (16-byte buffer loads), lk_march3.h
@@ -386,11 +386,12 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
     const int H = a.H, W = a.W;
     const int y0 = st.y0;                            // even (host)
     const int y1 = min(y0 + st.th, H);
-    const int nrows = y1 - y0;                       // even (H is even or the strip height is: host)
+    const int nrows = y1 - y0;                       // even, except in the last strip of an odd level (host: only a coarsest level, !HAS_UP): its
+                                                     // last step marches the row below the image as well -- zero products (F), store dropped (B)
     const int nm = nrows + 2 * R;                    // marched product rows: image rows y0-R .. y1-1+R
     const int yy0 = y0 - R;
     const int x0 = bx * XO - HL;                     // image column of block column 0 (even)
-    const int nsw = nm / 2;                          // steps in which F (and, one step later, S) has rows
+    const int nsw = (nm + 1) / 2;                    // steps in which F (and, one step later, S) has rows
     const int ns = nsw + 2 + C::LAG;                 // pipeline steps: B trails F by two (FW: F trails W by two)
     const int NS = (ns + UN - 1) / UN * UN;          // barriers per wave: padded to whole F groups (idle tail steps)
 
@@ -923,7 +924,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             __syncthreads();
         };
         for (int k = 0; k < R + 2 + C::LAG + (FW ? 1 : 0); ++k) __syncthreads();   // (FW: W / F prologue,) pipeline fill: no window sums yet
-        const int npairs = nrows / 2;
+        const int npairs = (nrows + 1) / 2;
         int p = 0;
         for (; p + TD <= npairs; p += TD) {                     // whole groups
             [&]<int... Ps>(std::integer_sequence<int, Ps...>) __attribute__((always_inline)) {

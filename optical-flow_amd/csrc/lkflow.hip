@@ -392,7 +392,7 @@ template <int WIN, int K>
 int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
 {
     using C = lk::SplitCfg<WIN, K>;
-    if ((a.W & 1) || (a.H & 1) || a.W < 2 || a.H <= C::R + C::PF + 1) return LK_NOT_TAKEN;   // odd / tiny levels: one-role kernel
+    if ((a.W & 1) || ((a.H & 1) && has_up) || a.W < 2 || a.H <= C::R + C::PF + 1) return LK_NOT_TAKEN;   // odd / tiny levels: one-role kernel
     const int gx = (a.W + C::XO - 1) / C::XO;
     const long long pmax = std::max(a.i1.pitch, std::max(a.u.pitch, a.v.pitch));
     const long long cap = (0x7fffffffLL / (pmax * 8) - 2 * C::R - 8) & ~1LL;   // (32-bit byte offsets from a strip's first row)
@@ -503,11 +503,13 @@ int launch_splitw(lkflow_ctx *ctx, const lk::LKArgs &a, int pairs, int win, hipS
 }
 
 // shapes the wave-specialised kernel takes (the rest -- odd or tiny levels -- runs the one-role kernel)
-bool split_applies(int win, int W, int H)
+// (odd heights only without a coarser level -- the coarsest level of a pyramid is the only one that can be odd: 3840 x 2160 / L5 and
+// 960 x 540 / L3 end in 240 x 135, where the one-role kernel took 0.044 ms at 21 x 21 and 0.12 ms at 25 x 25 for 8 / 32 pairs)
+bool split_applies(int win, int W, int H, bool has_up = true)
 {
     static const int split = knob("LKFLOW_SPLIT", 1);            // A/B: 0 = one-role kernel
     const int R = win / 2;
-    return split && win >= 5 && win <= LKFLOW_MAX_WIN && !(W & 1) && !(H & 1) && W >= 2 && H > R + LK_SPLIT_PF + 1;
+    return split && win >= 5 && win <= LKFLOW_MAX_WIN && !(W & 1) && (!(H & 1) || !has_up) && W >= 2 && H > R + LK_SPLIT_PF + 1;
 }
 
 // Windows 5..21 on even levels: run the warp of the level inside the wave-specialised LK kernel (lk_split.h, W role: the warped
@@ -720,7 +722,7 @@ int launch_lk(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, int win, hi
         else {
             rc = batch_applies(ctx, win, a.W, a.H) ? launch_batch(ctx, a, has_up, false, pairs, win, s, -1, 0) : LK_NOT_TAKEN;
             if (rc == LK_NOT_TAKEN)
-                rc = split_applies(win, a.W, a.H) ? launch_split(ctx, a, has_up, pairs, win, s) : LK_NOT_TAKEN;
+                rc = split_applies(win, a.W, a.H, has_up) ? launch_split(ctx, a, has_up, pairs, win, s) : LK_NOT_TAKEN;
             if (rc == LK_NOT_TAKEN) rc = launch_lk3(ctx, a, has_up, pairs, win, s);
         }
         if (rc) return rc;
@@ -849,7 +851,7 @@ int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok,
         snprintf(buf, n, "%s", knob("LKFLOW_W3_ONE_COLUMN", LKFLOW_W3_ONE_COLUMN) ? "lk::lk_w3x1f_kernel<true>" : "lk::lk_w3x2f_kernel");
     else if (win == 3 && !no_x2 && cols >= 2 && !(cols & 1)) snprintf(buf, n, "lk::lk_w3x2_kernel<%s>", up);
     else if (win == 3) snprintf(buf, n, "lk::lk_march3_kernel<3, 64, %s>", up);
-    else if (split_applies(win, cols, rows)) {
+    else if (split_applies(win, cols, rows, has_up != 0)) {
         lkflow_ctx dflt;                                         // default options; the CU count of device 0 if there is one
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess && ncu > 0) dflt.n_cu = ncu;
@@ -865,7 +867,7 @@ int lkflow_lk_kernel_name(int rows, int cols, int win, int has_up, int fused_ok,
 
 int lkflow_strip_plan(int rows, int halo_rows, long long column_strips, int slots, int lone_slots, long long out[3])
 {
-    if (!out || rows < 2 || (rows & 1) || halo_rows < 0 || column_strips < 1 || slots < 1 || lone_slots < 0) return LKFLOW_E_ARG;
+    if (!out || rows < 2 || halo_rows < 0 || column_strips < 1 || slots < 1 || lone_slots < 0) return LKFLOW_E_ARG;
     const StripPlan p = pick_strip_plan(rows, halo_rows, column_strips, slots, lone_slots, 0x7fffffff);
     out[0] = p.thA; out[1] = p.csA; out[2] = p.thB;
     return LKFLOW_OK;

@@ -136,6 +136,8 @@ def _split_tile(blk, nmain, gx, gyA, thA, tilesA, csA, csB, gyB, thB):
     (4320, 17, 82, 32, 256, 0),     # 8K level 0
     (160, 8, 3, 244, 512, 256),     # 240 x 160 stream
     (64, 4, 1, 1, 512, 256), (96, 8, 2, 3, 304, 0), (1080, 9, 18, 1, 256, 0), (1080, 3, 10, 48, 256, 0), (2, 1, 1, 1, 256, 0),
+    (135, 11, 3, 8, 512, 256),      # an odd coarsest level (3840 x 2160 / L5): the last strip's last step holds one image row
+    (153, 8, 2, 300, 512, 256), (77, 3, 1, 1000, 256, 0),
 ])
 def test_strip_plan_covers_every_tile_once(lkflow, rows, halo, gx, pairs, slots, lone):
     """The launch plan of the wave-specialised LK kernel (two strip heights in one launch): the planner's output walked
@@ -157,7 +159,7 @@ def test_strip_plan_covers_every_tile_once(lkflow, rows, halo, gx, pairs, slots,
             key = (pair, bx, y)
             assert key not in seen, (blk, seen[key], key)
             seen[key] = blk
-    assert len(seen) == nblk * (rows // 2)
+    assert len(seen) == nblk * ((rows + 1) // 2)
 
     def cost(n, th):                                   # pick_tile_rows' model: rounds x marched rows
         full, rem = divmod(n * -(-rows // th), slots)
@@ -171,4 +173,4 @@ def test_strip_plan_headline_shape(lkflow):
     """32 x 1080p, 15 x 15, fused level 0: 576 column strips on 256 one-workgroup CUs -> 512 whole columns + 64 in quarters."""
     assert lkflow.strip_plan(1080, 9, 576, 256, 0) == (1080, 512, 270)
     with pytest.raises(lkflow.LKFlowError):
-        lkflow.strip_plan(1081, 9, 576, 256, 0)
+        lkflow.strip_plan(1, 9, 576, 256, 0)

@@ -12,6 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-6        # ParallelBasicPyr.cpp:787 (absolute)
+TIGHT = 1e-9      # single level, smooth inputs: GPU vs oracle differ by summation order only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "optical-flow_amd")
 
@@ -350,6 +351,46 @@ def test_two_strip_heights_fuzz_many_small_pairs(lkflow, torch):
             torch.cuda.synchronize()
         assert not torch.isnan(U).any() and not torch.isnan(V).any(), (it, h, w, win, P)
         assert torch.equal(U, U1) and torch.equal(V, V1), (it, h, w, win, P)
+
+
+# ---------------------------------------------------------------------------- odd coarsest levels in the wave-specialised kernel
+@pytest.mark.parametrize("win", list(range(5, 32, 2)))
+def test_odd_height_coarsest_level_every_window(lkflow, oracle, torch, win):
+    """A coarsest level may have an odd height (3840 x 2160 / L5 and 960 x 540 / L3 end in 240 x 135): since round 4 the
+    wave-specialised kernel takes it (the last step of the last strip marches the row below the image: zero products, dropped
+    store).  Single-level LK on 135 x 240 and 77 x 130 (one strip) and with the strip height forced to 24 (last strip of 15 /
+    5 rows), 3 pairs: against the oracle, against the per-pixel kernel in the reference's summation order, and bitwise between
+    the two strip heights; then the same level as the coarsest of a 3-level pyramid (540 x 960 and 308 x 520) against the oracle."""
+    import synth
+    assert lkflow.lk_kernel_name(135, 240, win, has_up=False).startswith("lk::lk_split_kernel<%d, 2, false" % win)
+    assert lkflow.lk_kernel_name(135, 241, win, has_up=False).startswith("lk::lk_march3_kernel")
+    assert lkflow.lk_kernel_name(135, 240, win, has_up=True).startswith("lk::lk_march3_kernel")
+    for (h, w) in ((135, 240), (77, 130)):
+        if h <= win // 2 + 3:
+            continue
+        prs = [synth.frame_pair(h, w, seed=900 + win + k, shift=(0.7 + 0.2 * k, -0.4)) for k in range(3)]
+        a = np.stack([p[0] for p in prs]); b = np.stack([p[1] for p in prs])
+        da, db = dev(torch, a), dev(torch, b)
+        with lkflow.Context(0) as ctx:
+            u, v = ctx.lk_batch(da, db, win)
+            ctx.set_option(lkflow.LKFLOW_OPT_TILE_ROWS, 24)
+            u24, v24 = ctx.lk_batch(da, db, win)
+            ctx.set_option(lkflow.LKFLOW_OPT_TILE_ROWS, 0)
+            ctx.set_option(lkflow.LKFLOW_OPT_IMPL, 1)
+            un, vn = ctx.lk_batch(da, db, win)
+            torch.cuda.synchronize()
+        assert torch.equal(u, u24) and torch.equal(v, v24)
+        for k in range(3):
+            uo, vo = oracle.lucas_kanade(a[k], b[k], win)
+            assert np.abs(host(u)[k] - uo).max() <= TIGHT and np.abs(host(v)[k] - vo).max() <= TIGHT, (h, w, k)
+        assert (u - un).abs().max().item() <= TIGHT and (v - vn).abs().max().item() <= TIGHT
+    for (h, w) in ((540, 960), (308, 520)):
+        a, b = synth.frame_pair(h, w, seed=950 + win, shift=(1.1, -0.8))
+        with lkflow.Context(0) as ctx:
+            U, V = ctx.compute_batch(dev(torch, a)[None], dev(torch, b)[None], 3, win)
+            torch.cuda.synchronize()
+        Uo, Vo = oracle.coarse_to_fine(a, b, 3, win)
+        assert np.abs(host(U)[0] - Uo).max() <= TOL and np.abs(host(V)[0] - Vo).max() <= TOL, (h, w)
 
 
 # ---------------------------------------------------------------------------- the C-ABI frame-queue engine through ctypes
