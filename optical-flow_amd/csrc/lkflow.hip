@@ -97,6 +97,10 @@ struct lkflow_ctx {
     std::vector<long long> off_flow;  // level >= 1: u planes [pairs] then v planes [pairs]
     // resident blocks per CU of each kernel instantiation ON THIS DEVICE (occupancy query, first use)
     std::unordered_map<const void *, int> occ;
+    // launch plans of the wave-specialised kernel by (rows, halo, column strips, slots, lone slots, cap): a video loop asks for the
+    // same few again and again, and the planner's search grows with rows x column strips / slots
+    struct Plan { int H, R; long long nblk, slots, lone, cap; int thA; long long csA; int thB; };
+    std::vector<Plan> plans;
     // host-API staging (prev, next, U, V contiguous planes [+ two uint8 planes])
     double *stage = nullptr;
     size_t stage_bytes = 0;
@@ -307,6 +311,16 @@ inline StripPlan pick_strip_plan(int H, int R, long long nblk, long long slots, 
     return p;
 }
 
+inline StripPlan cached_strip_plan(lkflow_ctx *ctx, int H, int R, long long nblk, long long slots, long long lone_cus, long long cap)
+{
+    for (const auto &q : ctx->plans)
+        if (q.H == H && q.R == R && q.nblk == nblk && q.slots == slots && q.lone == lone_cus && q.cap == cap) return StripPlan{q.thA, q.csA, q.thB};
+    const StripPlan p = pick_strip_plan(H, R, nblk, slots, lone_cus, cap);
+    if (ctx->plans.size() >= 64) ctx->plans.clear();
+    ctx->plans.push_back(lkflow_ctx::Plan{H, R, nblk, slots, lone_cus, cap, p.thA, p.csA, p.thB});
+    return p;
+}
+
 // fills the tile fields of the wave-specialised kernel's arguments from a plan; returns the number of marching workgroups
 // (0: too many for a 32-bit grid)
 inline unsigned apply_strip_plan(lk::LKArgs &a, const StripPlan &p, int gx, long long nblk)
@@ -405,7 +419,7 @@ int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipS
     } else {
         const int bpc = has_up ? blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, true>, C::NT)
                                : blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, false>, C::NT);
-        plan = pick_strip_plan(a.H, C::R + 1, nblk, (long long)ctx->n_cu * bpc, bpc == 2 ? ctx->n_cu : 0, cap);
+        plan = cached_strip_plan(ctx, a.H, C::R + 1, nblk, (long long)ctx->n_cu * bpc, bpc == 2 ? ctx->n_cu : 0, cap);
         if (plan.thA > cap) plan = StripPlan{(int)cap, nblk, (int)cap};
     }
     const unsigned nmarch = apply_strip_plan(a, plan, gx, nblk);
@@ -459,7 +473,7 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s, i
         plan = StripPlan{th, nblk, th};
     } else {
         const int bpc = blocks_per_cu(ctx, lk::lk_split_kernel<WIN, K, true, true>, C::NT);
-        plan = pick_strip_plan(a.H, C::R + 2, nblk, (long long)ctx->n_cu * bpc, 0, cap);
+        plan = cached_strip_plan(ctx, a.H, C::R + 2, nblk, (long long)ctx->n_cu * bpc, 0, cap);
         if (plan.thA > cap) plan = StripPlan{(int)cap, nblk, (int)cap};
     }
     const unsigned nmarch = apply_strip_plan(a, plan, gx, nblk);
