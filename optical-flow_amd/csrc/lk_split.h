@@ -49,7 +49,7 @@
 // two-wave form was slower than warp + LK: section 4.4).
 //
 // Only additions in the window sums (flat regions give exactly 0 like the reference); same products, solve and pyrUp
-// expressions as lk_march3.h.  Host-checked: W even, H even below a coarser level (a coarsest level may be odd: see nrows),
+// expressions as lk_march3.h.  Host-checked: W and H even below a coarser level (a coarsest level may be odd: see nrows and half_fix),
 // H > R + PF + 1, even strip height (a step's row pair is an even and an odd output row); other shapes take lk_march3.h.  The LK_ABL_* macros are timing-only ablations (results wrong by
 // design) behind the records in profiles/r04_a_fused_warp_ab.txt; no shipped build defines them.
 #pragma once
@@ -681,11 +681,17 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             fstepw(std::integral_constant<int, 1>{}, t + 1);
         }
       } else {
-        const int xa = x0 + 2 * (m - 1);             // even; W even: the pair is all in or all out
+        const int xa = x0 + 2 * (m - 1);             // even.  W even: the pair is all in or all out; W odd (a coarsest level): the pair
+                                                     // (W - 1, W) is half in -- its load is clamped to (W - 2, W - 1), see half_fix below
         const int pitchb = (int)a.i1.pitch * 8;
-        const bool col_in = xa >= 0 && xa < W;
-        const bool all_col_in = __builtin_amdgcn_ballot_w64(!col_in) == 0;
+        const bool col_in = xa >= 0 && xa < W, col_in_b = xa >= 0 && xa + 1 < W;
+        const bool all_col_in = __builtin_amdgcn_ballot_w64(!col_in_b) == 0;
         const int xc = min(max(xa, 0), W - 2);
+        // W odd: the lane of the half pair has loaded (pixel W - 2, pixel W - 1) and wants pixel W - 1 as its FIRST column (its second
+        // column, W, lies outside: zero products).  Wave-uniform: one wave of the last column block has such a lane, no wave when W is even.
+        const bool half_lane = xa == W - 1;
+        const bool half_wave = __builtin_amdgcn_ballot_w64(half_lane) != 0;
+        auto half_fix = [&](double &va, double vb) __attribute__((always_inline)) { if (half_wave) va = half_lane ? vb : va; };
         const int row_lo = max(y0 - R - PF, 0);
         const long long img_bytes = ((long long)(H - 1 - row_lo) * a.i1.pitch + W) * 8;
         const __amdgpu_buffer_rsrc_t rI1 = buf_rsrc(a.i1.at(pair) + (long long)row_lo * a.i1.pitch, img_bytes);
@@ -712,6 +718,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             buf_ld2(rI1, vxc, ro, pa[0], pb[0]); buf_ld2(rI2, vxc, ro, pa[1], pb[1]);
             ro = img_row_off(yy0);
             buf_ld2(rI1, vxc, ro, ca[0], cb[0]); buf_ld2(rI2, vxc, ro, ca[1], cb[1]);
+            half_fix(pa[0], pb[0]); half_fix(pa[1], pb[1]); half_fix(ca[0], cb[0]); half_fix(ca[1], cb[1]);
             pl[0] = left_tap(pb[0]); pl[1] = left_tap(pb[1]);
             cl[0] = left_tap(cb[0]); cl[1] = left_tap(cb[1]);
         }
@@ -745,9 +752,9 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             double fyb = f2d_y(pa[0], pb[0], ca[0], cb[0]) + f2d_y(pa[1], pb[1], ca[1], cb[1]);
             const double ftb = f2d_neg(pa[0], pb[0], ca[0], cb[0]) + f2d_pos(pa[1], pb[1], ca[1], cb[1]);
             if (!(row_in && all_col_in)) {                  // rows / columns outside the image contribute 0 (wave-uniform test)
-                const bool keep = row_in && col_in;
+                const bool keep = row_in && col_in, keep_b = row_in && col_in_b;
                 fxa = keep ? fxa : 0.0; fya = keep ? fya : 0.0;
-                fxb = keep ? fxb : 0.0; fyb = keep ? fyb : 0.0;
+                fxb = keep_b ? fxb : 0.0; fyb = keep_b ? fyb : 0.0;
             }
             lk_d2 o;
             // per field: the two products as one 16-byte store, their sum (what S adds up for the shared part of the
@@ -769,6 +776,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
             for (int g = 0; g < 2; ++g) {
                 pl[g] = cl[g]; pa[g] = ca[g]; pb[g] = cb[g];
                 ca[g] = qa[(QS + 1) % PF][g]; cb[g] = qb[(QS + 1) % PF][g];
+                half_fix(ca[g], cb[g]);
                 cl[g] = left_tap(cb[g]);
             }
         };

@@ -406,7 +406,7 @@ template <int WIN, int K>
 int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
 {
     using C = lk::SplitCfg<WIN, K>;
-    if ((a.W & 1) || ((a.H & 1) && has_up) || a.W < 2 || a.H <= C::R + C::PF + 1) return LK_NOT_TAKEN;   // odd / tiny levels: one-role kernel
+    if ((((a.W | a.H) & 1) && has_up) || a.W < 2 || a.H <= C::R + C::PF + 1) return LK_NOT_TAKEN;   // tiny levels (odd ones under a coarser level do not exist): one-role kernel
     const int gx = (a.W + C::XO - 1) / C::XO;
     const long long pmax = std::max(a.i1.pitch, std::max(a.u.pitch, a.v.pitch));
     const long long cap = (0x7fffffffLL / (pmax * 8) - 2 * C::R - 8) & ~1LL;   // (32-bit byte offsets from a strip's first row)
@@ -517,13 +517,14 @@ int launch_splitw(lkflow_ctx *ctx, const lk::LKArgs &a, int pairs, int win, hipS
 }
 
 // shapes the wave-specialised kernel takes (the rest -- odd or tiny levels -- runs the one-role kernel)
-// (odd heights only without a coarser level -- the coarsest level of a pyramid is the only one that can be odd: 3840 x 2160 / L5 and
-// 960 x 540 / L3 end in 240 x 135, where the one-role kernel took 0.044 ms at 21 x 21 and 0.12 ms at 25 x 25 for 8 / 32 pairs)
+// (odd sizes only without a coarser level -- the coarsest level of a pyramid is the only one that can be odd: 3840 x 2160 / L5 and
+// 960 x 540 / L3 end in 240 x 135, where the one-role kernel took 0.044 ms at 21 x 21 and 0.12 ms at 25 x 25 for 8 / 32 pairs;
+// 1080 x 1080 / L4 ends in 135 x 135)
 bool split_applies(int win, int W, int H, bool has_up = true)
 {
     static const int split = knob("LKFLOW_SPLIT", 1);            // A/B: 0 = one-role kernel
     const int R = win / 2;
-    return split && win >= 5 && win <= LKFLOW_MAX_WIN && !(W & 1) && (!(H & 1) || !has_up) && W >= 2 && H > R + LK_SPLIT_PF + 1;
+    return split && win >= 5 && win <= LKFLOW_MAX_WIN && (!((W | H) & 1) || !has_up) && W >= 2 && H > R + LK_SPLIT_PF + 1;
 }
 
 // Windows 5..21 on even levels: run the warp of the level inside the wave-specialised LK kernel (lk_split.h, W role: the warped

@@ -356,16 +356,19 @@ def test_two_strip_heights_fuzz_many_small_pairs(lkflow, torch):
 # ---------------------------------------------------------------------------- odd coarsest levels in the wave-specialised kernel
 @pytest.mark.parametrize("win", list(range(5, 32, 2)))
 def test_odd_height_coarsest_level_every_window(lkflow, oracle, torch, win):
-    """A coarsest level may have an odd height (3840 x 2160 / L5 and 960 x 540 / L3 end in 240 x 135): since round 4 the
-    wave-specialised kernel takes it (the last step of the last strip marches the row below the image: zero products, dropped
-    store).  Single-level LK on 135 x 240 and 77 x 130 (one strip) and with the strip height forced to 24 (last strip of 15 /
+    """A coarsest level may have an odd height and / or width (3840 x 2160 / L5 and 960 x 540 / L3 end in 240 x 135, 1080 x 1080 /
+    L4 in 135 x 135): since round 4 the wave-specialised kernel takes it (the last step of the last strip marches the row below
+    the image: zero products, dropped store; the column pair (W - 1, W) is loaded clamped and re-seated).  Single-level LK on 135 x 240 and 77 x 130 (one strip) and with the strip height forced to 24 (last strip of 15 /
     5 rows), 3 pairs: against the oracle, against the per-pixel kernel in the reference's summation order, and bitwise between
     the two strip heights; then the same level as the coarsest of a 3-level pyramid (540 x 960 and 308 x 520) against the oracle."""
     import synth
     assert lkflow.lk_kernel_name(135, 240, win, has_up=False).startswith("lk::lk_split_kernel<%d, 2, false" % win)
-    assert lkflow.lk_kernel_name(135, 241, win, has_up=False).startswith("lk::lk_march3_kernel")
+    assert lkflow.lk_kernel_name(135, 241, win, has_up=False).startswith("lk::lk_split_kernel<%d, 2, false" % win)
     assert lkflow.lk_kernel_name(135, 240, win, has_up=True).startswith("lk::lk_march3_kernel")
-    for (h, w) in ((135, 240), (77, 130)):
+    assert lkflow.lk_kernel_name(136, 241, win, has_up=True).startswith("lk::lk_march3_kernel")
+    # odd widths too (1080 x 1080 / L4 ends in 135 x 135): the half-in column pair (W - 1, W); 221 = 2 x 110 + 1: the half pair is
+    # the first pair of a column block of its own; 127 / 129: it sits at the end / just past the F wave's 126 columns
+    for (h, w) in ((135, 240), (77, 130), (135, 135), (78, 131), (51, 221), (64, 127), (65, 129)):
         if h <= win // 2 + 3:
             continue
         prs = [synth.frame_pair(h, w, seed=900 + win + k, shift=(0.7 + 0.2 * k, -0.4)) for k in range(3)]
@@ -384,7 +387,7 @@ def test_odd_height_coarsest_level_every_window(lkflow, oracle, torch, win):
             uo, vo = oracle.lucas_kanade(a[k], b[k], win)
             assert np.abs(host(u)[k] - uo).max() <= TIGHT and np.abs(host(v)[k] - vo).max() <= TIGHT, (h, w, k)
         assert (u - un).abs().max().item() <= TIGHT and (v - vn).abs().max().item() <= TIGHT
-    for (h, w) in ((540, 960), (308, 520)):
+    for (h, w) in ((540, 960), (308, 520), (540, 540), (308, 524)):
         a, b = synth.frame_pair(h, w, seed=950 + win, shift=(1.1, -0.8))
         with lkflow.Context(0) as ctx:
             U, V = ctx.compute_batch(dev(torch, a)[None], dev(torch, b)[None], 3, win)
