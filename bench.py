@@ -552,7 +552,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # LKFLOW_BENCH_FORCE_PG=1 (tests only, never set by the driver): build the process group for ONE rank as well, so that a
+    # one-GPU box executes the RCCL leg of the N > 1 path for real (communicator init, barrier, all_reduce, the frame queue)
+    if world > 1 or os.environ.get("LKFLOW_BENCH_FORCE_PG") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
@@ -718,9 +720,10 @@ def main():
             out["stream_sharding"] = stream_extra
 
     if rank == 0:
-        if world == 1 and K == 1 and not args.graph and P >= 8 and not args.no_extras:
+        solo = world == 1 and dist is None                  # (a forced one-rank process group ran the stream extra instead)
+        if solo and K == 1 and not args.graph and P >= 8 and not args.no_extras:
             out["pipelined"] = pipelined_rate(lkf, torch, prev, nxt, U, V, levels, win, local_rank, world)
-        if world == 1 and not args.no_extras:
+        if solo and not args.no_extras:
             del prev, nxt, U, V
             torch.cuda.empty_cache()
             ceil_bps = copy_ceiling(torch, local_rank)
@@ -738,7 +741,7 @@ def main():
                 out["config_pacman"] = extra_config(lkf, torch, synth, "pacman", local_rank)         # BASELINE config 3's shape
             out["preprocess"] = preprocess_rate(ctx, torch, local_rank)
             out["video_pipeline"] = video_pipeline_rate(lkf, torch, local_rank)
-        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
+        if solo and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(cols, rows, levels, win)
         print(json.dumps(out), flush=True)
 

@@ -397,6 +397,12 @@ struct LKArgs {
     // rows.  One height: tilesA = nmain, csB = 0.
     unsigned tilesA, csA, csB;
     int gyB, thB;
+    // lk_split: image column where the OUTPUT columns of column block 0 start (even, <= R; 0 in every other kernel).  The frame of
+    // width R belongs to the frame workgroups, so the marching blocks only need to cover columns R .. W - R - 1: starting block 0
+    // at R & ~1 instead of 0 saves a whole column block when W - 2R fits one block fewer than W does (120 columns at 15 x 15: one
+    // block of 110 instead of two; 1920 and 960 at 21 x 21: 18 / 9 instead of 19 / 10).  Same lanes' arithmetic for every
+    // column (column parity is kept), so results do not depend on it.
+    int xorg;
 };
 
 // workgroup -> (pair, column block, first row, rows per strip) of the wave-specialised kernel: XCD-aware within each phase

@@ -390,7 +390,7 @@ __global__ __launch_bounds__((SplitCfg<WIN, K, FW>::NT), (SplitCfg<WIN, K, FW>::
                                                      // last step marches the row below the image as well -- zero products (F), store dropped (B)
     const int nm = nrows + 2 * R;                    // marched product rows: image rows y0-R .. y1-1+R
     const int yy0 = y0 - R;
-    const int x0 = bx * XO - HL;                     // image column of block column 0 (even)
+    const int x0 = a.xorg + bx * XO - HL;            // image column of block column 0 (even; LKArgs::xorg)
     const int nsw = (nm + 1) / 2;                    // steps in which F (and, one step later, S) has rows
     const int ns = nsw + 2 + C::LAG;                 // pipeline steps: B trails F by two (FW: F trails W by two)
     const int NS = (ns + UN - 1) / UN * UN;          // barriers per wave: padded to whole F groups (idle tail steps)

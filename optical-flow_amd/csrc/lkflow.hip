@@ -401,13 +401,24 @@ struct BorderFork {
     }
 };
 
+// Column blocks of the wave-specialised kernel and the column its block 0 starts its outputs at (LKArgs::xorg): the marching
+// blocks cover the columns R .. W - R - 1 only (the frame of width R is the frame workgroups'), from the even column R & ~1 on.
+template <typename C>
+int split_column_blocks(lk::LKArgs &a)
+{
+    static const int shifted = knob("LKFLOW_SPLIT_XORG", 1);   // (A/B knob of a debug-knob build: 0 = blocks from column 0)
+    a.xorg = (shifted && a.W > 2 * C::R) ? (C::R & ~1) : 0;
+    const int need = a.xorg ? a.W - C::R - a.xorg : a.W;       // output columns xorg .. W - R - 1
+    return std::max(1, (need + C::XO - 1) / C::XO);
+}
+
 // Wave-specialised kernel (lk_split.h): K*64-column blocks, K PE waves + 5 window-sum waves
 template <int WIN, int K>
 int launch_split_win(lkflow_ctx *ctx, lk::LKArgs a, bool has_up, int pairs, hipStream_t s)
 {
     using C = lk::SplitCfg<WIN, K>;
     if ((((a.W | a.H) & 1) && has_up) || a.W < 2 || a.H <= C::R + C::PF + 1) return LK_NOT_TAKEN;   // tiny levels (odd ones under a coarser level do not exist): one-role kernel
-    const int gx = (a.W + C::XO - 1) / C::XO;
+    const int gx = split_column_blocks<C>(a);
     const long long pmax = std::max(a.i1.pitch, std::max(a.u.pitch, a.v.pitch));
     const long long cap = (0x7fffffffLL / (pmax * 8) - 2 * C::R - 8) & ~1LL;   // (32-bit byte offsets from a strip's first row)
     if (cap < 2) return LKFLOW_E_ARG;
@@ -462,7 +473,7 @@ int launch_splitw_win(lkflow_ctx *ctx, lk::LKArgs a, int pairs, hipStream_t s, i
     // the W role addresses a whole image plane with 32-bit byte offsets and one pitch for both images
     // (forms row * pitch with a 24-bit multiply and clamps unsaturated tap coordinates: see the W role)
     if (a.i1.pitch != a.i2.pitch || (long long)a.H * a.i1.pitch * 8 > 0x7fffffffLL || a.i1.pitch * 8 >= (1 << 24) || a.H > 32766 || a.W > 32766) return LK_NOT_TAKEN;
-    const int gx = (a.W + C::XO - 1) / C::XO;
+    const int gx = split_column_blocks<C>(a);
     const long long pmax = std::max(a.u.pitch, a.v.pitch);
     const long long cap = (0x7fffffffLL / (pmax * 8) - 2 * C::R - 8) & ~1LL;
     if (cap < 2) return LKFLOW_E_ARG;

@@ -422,3 +422,66 @@ def test_stream_engine_ctypes_matches_compute_video(gpu_ctx, lkflow, torch):
             with pytest.raises(lkflow.LKFlowError):
                 eng.push(frames[:1])
     assert want[:, 0].sum() > 100                              # the stream really moves
+
+
+# ---------------------------------------------------------------------------- the RCCL leg of the N > 1 bench path, one rank
+def test_bench_under_the_driver_launcher_over_rccl_single_rank():
+    """The driver's N > 1 launch form (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`) at N = 1 with LKFLOW_BENCH_FORCE_PG=1: the process group is built on the nccl
+    (= RCCL) backend for the one rank, so communicator set-up, dist.barrier(), the MAX all_reduce of the timed region and the
+    frame-queue extra (scatter / flow / gather with the device as the wire) all EXECUTE on RCCL on this box -- what the gloo
+    rehearsals cannot show.  Two ranks on one GPU are not possible under RCCL (duplicate device), so this is as far as a
+    one-GPU box goes."""
+    import json
+    import socket
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, LKFLOW_BENCH_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "1", "--pairs", "4", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0
+    ss = rec["stream_sharding"]
+    assert "error" not in ss, ss
+    assert ss["rows_gathered"] == [ss["pairs"], 3], ss
+
+
+# ---------------------------------------------------------------------------- column blocks that start at the frame's inner edge
+@pytest.mark.parametrize("win", [5, 15, 21, 31])
+def test_column_blocks_start_inside_the_frame(lkflow, oracle, torch, win):
+    """LKArgs::xorg: block 0 of the wave-specialised kernel starts its outputs at column R & ~1 and the launch holds
+    ceil((W - R - xorg) / XO) column blocks.  Widths on both sides of the block-count edges (XO = 126 - 2 HL columns per block; one
+    and two blocks' worth, +- 2), single level, 2 levels unfused (strip height forced) and fused, against the oracle: a column
+    lost between two blocks or at the right edge would read as an untouched (NaN-filled) or wrong output column."""
+    import synth
+    R = win // 2
+    HL = R + (R & 1)
+    XO = 126 - 2 * HL
+    org = R & ~1
+    for nblk in (1, 2):
+        for w in (nblk * XO + R + org - 2, nblk * XO + R + org, nblk * XO + R + org + 2):
+            w &= ~3                                            # even at the coarser level too
+            h = 2 * (2 * R + 8)
+            a, b = synth.frame_pair(h, w, seed=900 + win + w, shift=(0.8, -1.1))
+            da, db = dev(torch, a)[None], dev(torch, b)[None]
+            with lkflow.Context(0) as ctx:
+                u, v = ctx.lk_batch(da, db, win)
+                outs = []
+                for fuse in (0, 1):
+                    ctx.set_option(lkflow.LKFLOW_OPT_FUSE_WARP, fuse)
+                    outs.append(ctx.compute_batch(da, db, 2, win))
+                torch.cuda.synchronize()
+            uo, vo = oracle.lucas_kanade(a, b, win)
+            assert np.abs(host(u)[0] - uo).max() <= TIGHT and np.abs(host(v)[0] - vo).max() <= TIGHT, (win, w)
+            Uo, Vo = oracle.coarse_to_fine(a, b, 2, win)
+            for U, V in outs:
+                assert np.abs(host(U)[0] - Uo).max() <= TOL and np.abs(host(V)[0] - Vo).max() <= TOL, (win, w)
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (win, w)
