@@ -588,7 +588,10 @@ def main():
         assert not args.graph, "--graph and --inflight are separate experiments"
         bounds = [P * k // K for k in range(K + 1)]
         ctxs = [ctx] + [lkf.Context(local_rank) for _ in range(K - 1)]
-        streams = [torch.cuda.Stream() for _ in range(K)]
+        # (experiment knob: LKFLOW_BENCH_INFLIGHT_PRIO="-1,0" gives the chunks' streams HIP priorities -- a high-priority chunk's
+        # one-workgroup-per-CU LK launches then leave only their spare registers to the other chunk's pyramid kernels)
+        prios = [int(x) for x in os.environ.get("LKFLOW_BENCH_INFLIGHT_PRIO", "").split(",") if x.strip()]
+        streams = [torch.cuda.Stream(priority=prios[k % len(prios)]) if prios else torch.cuda.Stream() for k in range(K)]
         for k in range(K):
             ctxs[k].reserve(rows, cols, levels, bounds[k + 1] - bounds[k])
             streams[k].wait_stream(stream)
