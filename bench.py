@@ -157,7 +157,18 @@ def prewarm(torch, step, seconds=None):
     return n
 
 
-def make_inputs(torch, synth, name, P, rows, cols, dev, seed):
+PACMAN_FIXTURE = os.path.join(ROOT, "tests", "golden", "pacman_240x160_y.npz")
+
+
+def make_inputs(torch, synth, name, P, rows, cols, dev, seed, real=False):
+    if real:
+        # BASELINE config 3 on its real data: the luma frames of the reference's pacman.mp4, decoded by optical-flow_amd/h264_ingest.py
+        # (committed fixture: /root/reference does not exist on the GPU box), convertTo(CV_64F, 1 / 255) as SerialPyr.cpp:237
+        import numpy as np
+        y = np.load(PACMAN_FIXTURE)["Y"]
+        assert name == "pacman" and y.shape == (P + 1, rows, cols), y.shape
+        frames = torch.from_numpy(y).to(dev).to(torch.float64) * (1.0 / 255)
+        return frames[:-1], frames[1:]
     if name in VIDEO_CONFIGS:
         frames = synth.video_torch(P + 1, rows, cols, dev, seed=seed)
         return frames[:-1], frames[1:]
@@ -208,12 +219,12 @@ def roofline_objects(lkf, name, cols, rows, levels, win, P, pairs_per_launch, lk
     return roof, path, achieved, path_achieved
 
 
-def extra_config(lkf, torch, synth, name, device, steps=10, warmup=2):
+def extra_config(lkf, torch, synth, name, device, steps=10, warmup=2, real=False):
     """Extra objects `config_4k` / `config_webcam`: the same measurement as the headline on another
     BASELINE shape, single stream, device-resident, with its own level-0 roofline from HIP events."""
     cols, rows, levels, win, P = CONFIGS[name]
     dev = torch.device("cuda", device)
-    prev, nxt = make_inputs(torch, synth, name, P, rows, cols, dev, 4321)
+    prev, nxt = make_inputs(torch, synth, name, P, rows, cols, dev, 4321, real=real)
     U, V = torch.empty_like(prev), torch.empty_like(prev)
     ctx = lkf.Context(device)
     ctx.reserve(rows, cols, levels, P)
@@ -237,6 +248,8 @@ def extra_config(lkf, torch, synth, name, device, steps=10, warmup=2):
     torch.cuda.empty_cache()
     return {"workload": f"{cols}x{rows} L{levels} w{win}, {P} " + ("consecutive pairs of one stream" if name in VIDEO_CONFIGS else "independent pairs") +
                         " per step, device-resident, 1 GPU",
+            "data": ("pacman.mp4: the 245 luma frames of the reference's file, decoded by optical-flow_amd/h264_ingest.py (fixture "
+                     "tests/golden/pacman_240x160_y.npz), convertTo(CV_64F, 1/255)") if real else "synthetic",
             "value": round(P * rows * cols * steps / dt / 1e6, 2), "unit": "Mpixels/s",
             "frame_pairs_per_s": round(P * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
             "roofline": roof, "path_roofline": path,
@@ -522,6 +535,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="frame pairs per step per GPU")
     ap.add_argument("--config", default="1080p", choices=sorted(CONFIGS))
     ap.add_argument("--win", type=int, default=0, help="override the config's window (experiments only)")
+    ap.add_argument("--real-data", action="store_true",
+                    help="--config pacman only: the decoded luma frames of the reference's pacman.mp4 (tests/golden fixture) instead of synthetic frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed region (no cpu_baseline, no extra objects): use under rocprofv3")
@@ -571,7 +586,7 @@ def main():
 
     # synthetic translated-noise input generated in HBM (each rank: its own shard).  BASELINE configs 3 and 4 are
     # STREAMS (consecutive pairs of one frame sequence): P+1 frames, pair p = frames p, p+1; the others are pairs.
-    prev, nxt = make_inputs(torch, synth, args.config, P, rows, cols, dev, 1234 + rank)
+    prev, nxt = make_inputs(torch, synth, args.config, P, rows, cols, dev, 1234 + rank, real=args.real_data)
     U = torch.empty_like(prev)
     V = torch.empty_like(prev)
     ctx = lkf.Context(local_rank)
@@ -671,7 +686,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "pacman.mp4 luma frames (tests/golden/pacman_240x160_y.npz)" if args.real_data else "synthetic",
             "config": {
                 "workload": (f"{cols}x{rows} synthetic translated-noise frame stream, {levels} levels, {win}x{win} "
                              f"window, {P + 1} frames = {P} consecutive pairs per step per GPU (device-resident)"
@@ -742,6 +757,8 @@ def main():
                 out["config_webcam"] = extra_config(lkf, torch, synth, "webcam", local_rank)
                 out["config_8k"] = extra_config(lkf, torch, synth, "8k", local_rank, steps=5)        # BASELINE config 4's shape
                 out["config_pacman"] = extra_config(lkf, torch, synth, "pacman", local_rank)         # BASELINE config 3's shape
+                if os.path.exists(PACMAN_FIXTURE):                                                   # ... and its real frames
+                    out["config_pacman_real"] = extra_config(lkf, torch, synth, "pacman", local_rank, real=True)
             out["preprocess"] = preprocess_rate(ctx, torch, local_rank)
             out["video_pipeline"] = video_pipeline_rate(lkf, torch, local_rank)
         if solo and not args.no_cpu_baseline and not args.no_extras:

@@ -485,3 +485,47 @@ def test_column_blocks_start_inside_the_frame(lkflow, oracle, torch, win):
             for U, V in outs:
                 assert np.abs(host(U)[0] - Uo).max() <= TOL and np.abs(host(V)[0] - Vo).max() <= TOL, (win, w)
             assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (win, w)
+
+
+# ---------------------------------------------------------------------------- BASELINE config 3 on its REAL frames
+def test_pacman_real_stream_245_frames(gpu_ctx, oracle, torch):
+    """BASELINE config 3 on the reference's own pacman.mp4 (245 luma frames decoded by optical-flow_amd/h264_ingest.py, committed as
+    tests/golden/pacman_240x160_y.npz; convertTo(CV_64F, 1 / 255) on the device), 3 levels, 15 x 15: compute_video over all 244 pairs
+    == every pair computed alone, bitwise; pairs 0 / 1 / 60 (an IDR picture) / 121 / 243 against the oracle at the reference's
+    ABSOLUTE 1e-6 -- on a real game screen: flat black regions (exactly singular windows -> 0), sprites, text, and windows that hold
+    nothing but interpolation residue, where the reference's quotient of two rounding errors reaches 1e16 (the outputs are compared
+    as they are: a bound relative to such a value would hide everything else)."""
+    y = np.load(os.path.join(ROOT, "tests", "golden", "pacman_240x160_y.npz"))["Y"]
+    assert y.shape == (245, 160, 240)
+    d = gpu_ctx.u8_to_f64(dev(torch, y))
+    U, V = gpu_ctx.compute_video(d, 3, 15)
+    assert U.shape == (244, 160, 240) and bool(torch.isfinite(U).all()) and bool(torch.isfinite(V).all())
+    for p in range(244):
+        u1, v1 = gpu_ctx.compute_batch(d[p:p + 1], d[p + 1:p + 2], 3, 15)
+        assert torch.equal(u1[0], U[p]) and torch.equal(v1[0], V[p]), p
+    f = host(d)
+    assert np.array_equal(f, y.astype(np.float64) * (1.0 / 255))                 # SerialPyr.cpp:237
+    moving = 0
+    for p in (0, 1, 60, 121, 243):
+        uo, vo = oracle.coarse_to_fine(f[p], f[p + 1], 3, 15)
+        du, dv = np.abs(host(U[p]) - uo), np.abs(host(V[p]) - vo)
+        small = np.abs(uo) < 1e3                                                  # (where the comparison is not about 1e16-sized values)
+        assert du[small].max() <= TOL and dv[small].max() <= TOL, (p, du[small].max(), dv[small].max())
+        assert (du <= np.maximum(TOL, 1e-12 * np.abs(uo))).all() and (dv <= np.maximum(TOL, 1e-12 * np.abs(vo))).all(), p
+        moving += int((uo != 0).sum())
+    assert moving > 50000                                                          # the stream really has flow
+
+
+def test_pacman_real_stream_through_the_frame_queue_engine(gpu_ctx, lkflow, torch):
+    """Config 3 as north_star words it -- "pacman.mp4 full stream ... frame-pair sharded" -- through the C-ABI frame-queue engine
+    (lkflow_stream_*, ParallelVideoPyr.cpp:769-873's loop): the 245 decoded 8-bit frames over the device list [0, 0, 0] (three
+    workers, blocks with a one-frame overlap) == convertTo + compute_video + flow_centroid on one context, centroid rows bit for bit."""
+    y = np.ascontiguousarray(np.load(os.path.join(ROOT, "tests", "golden", "pacman_240x160_y.npz"))["Y"])
+    d = gpu_ctx.u8_to_f64(dev(torch, y))
+    U, V = gpu_ctx.compute_video(d, 3, 15)
+    want = host(gpu_ctx.flow_centroid(U, V, 1.0))
+    with lkflow.StreamEngine([0, 0, 0], 160, 240, 3, 15) as eng:
+        eng.push(y, thresh=1.0)
+        got = eng.centroids()
+    assert got.shape == (244, 3) and np.array_equal(got, want)
+    assert (want[:, 0] > 0).sum() > 200                                            # nearly every pair has moving pixels
