@@ -1233,3 +1233,17 @@ def decode_mp4(path, with_chroma=False, progress=None):
     if not with_chroma:
         return Yv
     return Yv, np.stack(cbs)[:, ct:H // 2 - cb, cl:W // 2 - cr], np.stack(crs)[:, ct:H // 2 - cb, cl:W // 2 - cr], dec.stats
+
+
+def yuv420_to_bgr(y, cb, cr):
+    """Decoded YCbCr 4:2:0 planes ([n, H, W], [n, H/2, W/2] x 2, uint8) -> BGR frames uint8 [n, H, W, 3], the layout
+    cv::VideoCapture::read hands the reference (ParallelVideoPyr.cpp:776).  ITU-R BT.601 limited range, the usual 8-bit integer
+    form (298 / 409 / 100 / 208 / 516, >> 8), chroma replicated 2 x 2.  UNPINNED like the decoder: the reference's route is
+    libswscale, whose chroma up-sampling filter and rounding are not reproduced here."""
+    c = y.astype(np.int32) - 16
+    d = np.repeat(np.repeat(cb.astype(np.int32) - 128, 2, axis=-2), 2, axis=-1)
+    e = np.repeat(np.repeat(cr.astype(np.int32) - 128, 2, axis=-2), 2, axis=-1)
+    r = (298 * c + 409 * e + 128) >> 8
+    g = (298 * c - 100 * d - 208 * e + 128) >> 8
+    b = (298 * c + 516 * d + 128) >> 8
+    return np.clip(np.stack([b, g, r], axis=-1), 0, 255).astype(np.uint8)

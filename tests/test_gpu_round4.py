@@ -529,3 +529,36 @@ def test_pacman_real_stream_through_the_frame_queue_engine(gpu_ctx, lkflow, torc
         got = eng.centroids()
     assert got.shape == (244, 3) and np.array_equal(got, want)
     assert (want[:, 0] > 0).sum() > 200                                            # nearly every pair has moving pixels
+
+
+def test_reference_video_loop_on_the_real_pacman_frames(gpu_ctx, oracle, torch):
+    """The reference's whole per-frame loop (ParallelVideoPyr.cpp:776-873) on real video instead of a synthetic gesture: six decoded
+    BGR frames of pacman.mp4 (h264_ingest.yuv420_to_bgr of the fixture's planes) -> resize to 1080 x 1080 INTER_CUBIC (:778) ->
+    GaussianBlur 9 x 9 + BGR2GRAY (:786-787) -> cur - 0.3 prev, threshold, Sobel, dilate / erode (:800-813) -> coarseToFineEstimation with
+    getMaxLayer = 4 levels, 3 x 3 (:832) -> |flow| centroid (:845-873).  Every stage equals the oracle's byte for byte, the flow of both
+    checked pairs at every pixel (3 x 3: the reference's own summation order), and the centroid sums exactly."""
+    sys_path = os.path.join(ROOT, "optical-flow_amd")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import h264_ingest
+    f = np.load(os.path.join(ROOT, "tests", "golden", "pacman_240x160_y.npz"))
+    sel = slice(100, 106)
+    bgr = h264_ingest.yuv420_to_bgr(f["Y"][sel], f["Cb"][sel], f["Cr"][sel])          # [6, 160, 240, 3]
+    big = gpu_ctx.resize_cubic(dev(torch, bgr), 1080, 1080)
+    big_o = np.stack([oracle.resize_cubic_bgr8(bgr[k], 1080, 1080) for k in range(6)])
+    assert np.array_equal(host(big), big_o)
+    edges = gpu_ctx.preprocess_bgr(big)                                                # [5, 1080, 1080] float64
+    gray = [oracle.blur_gray_bgr8(big_o[k]) for k in range(6)]
+    want = [oracle.edge_map_u8(oracle.frame_diff_u8(gray[k + 1], gray[k], 0.3), 10) for k in range(5)]
+    for k in range(5):
+        assert np.array_equal(host(edges[k]), want[k]), k
+    assert 0.5 < float((host(edges) == 0).mean()) < 0.9999 and host(edges).max() > 100.0
+    U, V = gpu_ctx.compute_video(edges, 4, 3)
+    for p in (0, 3):
+        uo, vo = oracle.coarse_to_fine(want[p], want[p + 1], 4, 3)
+        assert np.array_equal(host(U[p]), uo, equal_nan=True) and np.array_equal(host(V[p]), vo, equal_nan=True), p
+    rows = host(gpu_ctx.flow_centroid(U, V, 20.0))
+    for p in (0, 3):
+        assert tuple(rows[p]) == tuple(oracle.flow_centroid(host(U[p]), host(V[p]), 20.0)), (p, rows[p])
+    assert rows[:, 0].max() > 0
