@@ -93,3 +93,56 @@ def test_decoder_reproduces_the_fixture_and_consumes_every_slice():
     assert stats["slice_bits_left"] == 0
     assert sum(stats[k] for k in stats if k != "slice_bits_left") == 245 * 150           # every macroblock of every picture
     assert cb.shape == (245, 80, 120) and 100 < cb.mean() < 156 and 100 < cr.mean() < 156   # chroma planes near neutral
+
+
+# ---------------------------------------------------------------------------------------------- the C-ABI / C++ reader
+PKG = os.path.join(ROOT, "optical-flow_amd")
+INGEST_LIB = os.path.join(PKG, "liblkingest.so")
+
+
+def _ingest_lib():
+    import ctypes
+    if not os.path.exists(INGEST_LIB):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g.build_ingest()
+    return ctypes.CDLL(INGEST_LIB)
+
+
+def test_ingest_library_exports_every_declared_symbol():
+    """include/lkingest.h <-> optical-flow_amd/liblkingest.so (host-only, g++): every declared function is exported; the library does
+    not link the HIP runtime, the flow library or the oracle; a missing file is LKINGEST_E_IO, a NULL argument LKINGEST_E_ARG."""
+    import ctypes
+    import re
+    import subprocess
+    L = _ingest_lib()
+    hdr = open(os.path.join(ROOT, "include", "lkingest.h")).read()
+    names = sorted(set(re.findall(r"\b(lkingest_[a-z_]+)\s*\(", hdr)))
+    assert len(names) == 6, names
+    for n in names:
+        assert hasattr(L, n), n
+    needed = subprocess.run(["readelf", "-d", INGEST_LIB], capture_output=True, text=True).stdout
+    assert "amdhip" not in needed and "lkflow" not in needed and "oracle" not in needed
+    h = ctypes.c_void_p()
+    assert L.lkingest_open(ctypes.byref(h), b"/nonexistent/file.mp4") == -2 and not h.value
+    assert L.lkingest_open(None, b"x") == -1
+    assert L.lkingest_info(None, None, None, None) == -1
+
+
+@pytest.mark.skipif(not os.path.exists(MP4), reason="the reference's pacman.mp4 is not on this machine (GPU box)")
+def test_cpp_reader_equals_the_python_decoder(tmp_path):
+    """tests/cpp/video_file_check.cpp: lkflow::VideoFile (include/lkingest.hpp over the C ABI; a second, scalar implementation of
+    the decoder in C++) reads the reference's file like the reference's loop reads its capture; all 245 luma planes equal the
+    Python decoder's fixture byte for byte, the first BGR frame equals yuv420_to_bgr of the fixture's planes."""
+    import subprocess
+    _ingest_lib()
+    exe = str(tmp_path / "video_file_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "video_file_check.cpp"), "-o", exe, "-L", PKG, "-llkingest", f"-Wl,-rpath,{PKG}"])
+    luma, bgr = str(tmp_path / "luma.u8"), str(tmp_path / "bgr.u8")
+    r = subprocess.run([exe, MP4, luma, bgr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "240 x 160, 245 frames" in r.stdout and "frames read: 245" in r.stdout
+    f = np.load(FIXTURE)
+    assert np.array_equal(np.fromfile(luma, np.uint8).reshape(245, 160, 240), f["Y"])
+    assert np.array_equal(np.fromfile(bgr, np.uint8).reshape(160, 240, 3), h.yuv420_to_bgr(f["Y"][:1], f["Cb"][:1], f["Cr"][:1])[0])
