@@ -583,6 +583,12 @@ def pred_plane(top, left, tl, n):
 
 
 # ------------------------------------------------------------------------------------------------ picture decoding
+def _next_qp(qp, delta):
+    if not -26 <= delta <= 25:                               # 7.4.5
+        raise ValueError("mb_qp_delta out of range")
+    return (qp + delta + 52) % 52
+
+
 class Picture:
     def __init__(self, mb_w, mb_h):
         self.mb_w, self.mb_h = mb_w, mb_h
@@ -651,6 +657,8 @@ class Decoder:
                         raise NotImplementedError("memory_management_control_operation %d" % op)
                     h["mmco"].append((op, b.ue()))
         h["qp"] = pps["init_qp"] + b.se()
+        if not 0 <= h["qp"] <= 51:
+            raise ValueError("slice QP out of range")
         h["deblock"], h["alpha_off"], h["beta_off"] = 0, 0, 0
         if pps["deblock_control"]:
             h["deblock"] = b.ue()
@@ -947,7 +955,7 @@ class Decoder:
                     cbp = (((intra_type - 1) // 4) % 3) << 4 | (15 if intra_type >= 13 else 0)
                     chroma_mode = b.ue()
                 if cbp > 0 or intra_type != 0:
-                    qp = (qp + b.se() + 52) % 52
+                    qp = _next_qp(qp, b.se())
                 mb_qp[mb] = qp
                 qpc_ = qpc_of(qp)
                 x0, y0 = 16 * mbx, 16 * mby
@@ -1062,7 +1070,7 @@ class Decoder:
                         inter_pred(mbx, mby, bx0 + px, by0 + py, w4, h4, ref, mv)
                 cbp = CBP_INTER[b.ue()]
                 if cbp > 0:
-                    qp = (qp + b.se() + 52) % 52
+                    qp = _next_qp(qp, b.se())
                 mb_qp[mb] = qp
                 qpc_ = qpc_of(qp)
                 for k in range(16):

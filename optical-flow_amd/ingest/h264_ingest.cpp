@@ -416,6 +416,7 @@ struct Decoder {
                 for (;;) { const int op = (int)b.ue(); if (op == 0) break; if (op != 1) throw Unsupported("memory_management_control_operation"); h.mmco.push_back({op, (int)b.ue()}); }
         }
         h.qp = pps.init_qp + b.se();
+        if (h.qp < 0 || h.qp > 51) throw BadStream("slice QP out of range");
         if (pps.deblock_control) { h.deblock = (int)b.ue(); if (h.deblock != 1) { h.alpha_off = 2 * b.se(); h.beta_off = 2 * b.se(); } }
         if (first_mb != 0) throw Unsupported("several slices per picture");
         return h;
@@ -458,6 +459,12 @@ struct Decoder {
 };
 
 // ---------------------------------------------------------------------------------------------- slice data (7.3.4, 7.3.5, 8.3, 8.4)
+inline int next_qp(int qp, int delta)      // 7.4.5: mb_qp_delta is in -26 .. 25
+{
+    if (delta < -26 || delta > 25) throw BadStream("mb_qp_delta out of range");
+    return (qp + delta + 52) % 52;
+}
+
 void Decoder::decode_slice(Bits &b, const SliceHdr &h, Picture &pic, const std::vector<std::shared_ptr<Picture>> &reflist)
 {
     const int nmb = mb_w * mb_h, C4w = W4 / 2;
@@ -634,7 +641,7 @@ void Decoder::decode_slice(Bits &b, const SliceHdr &h, Picture &pic, const std::
                 cbp = ((((intra_type - 1) / 4) % 3) << 4) | (intra_type >= 13 ? 15 : 0);
                 chroma_mode = (int)b.ue();
             }
-            if (cbp > 0 || intra_type != 0) qp = (qp + b.se() + 52) % 52;
+            if (cbp > 0 || intra_type != 0) qp = next_qp(qp, b.se());
             mb_qp[mb] = qp;
             const int qpc_ = qpc_of(qp), x0 = 16 * mbx, y0 = 16 * mby;
             if (intra_type == 0) {
@@ -730,7 +737,7 @@ void Decoder::decode_slice(Bits &b, const SliceHdr &h, Picture &pic, const std::
             const unsigned c = b.ue();
             if (c > 47) throw BadStream("coded_block_pattern");
             const int cbp = CBP_INTER[c];
-            if (cbp > 0) qp = (qp + b.se() + 52) % 52;
+            if (cbp > 0) qp = next_qp(qp, b.se());
             mb_qp[mb] = qp;
             for (int k = 0; k < 16; ++k) {
                 const int x4 = BLK_X[k], y4 = BLK_Y[k];
@@ -834,6 +841,7 @@ std::shared_ptr<Picture> Decoder::decode_nal(const uint8_t *nal, size_t len)
     Bits b(nal + 1, len - 1);
     const SliceHdr h = slice_header(b, nal_type, nal_ref_idc);
     if (h.idr) refs.clear();
+    if (sps.mb_w < 1 || sps.mb_h < 1 || sps.mb_w > 512 || sps.mb_h > 512) throw BadStream("picture size out of range");   // (an in-band SPS)
     mb_w = sps.mb_w; mb_h = sps.mb_h; W4 = 4 * mb_w; H4 = 4 * mb_h;
     auto pic = std::make_shared<Picture>();
     pic->Y.init(16 * mb_w, 16 * mb_h);
@@ -864,21 +872,28 @@ std::shared_ptr<Picture> Decoder::decode_nal(const uint8_t *nal, size_t len)
 }
 
 // ---------------------------------------------------------------------------------------------- ISO-BMFF sample tables
-inline uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
-inline uint64_t be64(const uint8_t *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+// every read of the file goes through a bounds check: a truncated or damaged file is an error status, never an out-of-range access
+struct FileView {
+    const std::vector<uint8_t> &f;
+    uint8_t u8(size_t o) const { if (o >= f.size()) throw BadStream("box past the end of the file"); return f[o]; }
+    uint32_t u32(size_t o) const { if (o + 4 > f.size() || o + 4 < o) throw BadStream("box past the end of the file"); return ((uint32_t)f[o] << 24) | ((uint32_t)f[o + 1] << 16) | ((uint32_t)f[o + 2] << 8) | f[o + 3]; }
+    uint64_t u64(size_t o) const { return ((uint64_t)u32(o) << 32) | u32(o + 4); }
+    bool is(size_t o, const char *four) const { return o + 4 <= f.size() && std::memcmp(&f[o], four, 4) == 0; }
+};
 
-struct Box { uint32_t type; size_t lo, hi; };
-bool find_box(const std::vector<uint8_t> &f, size_t lo, size_t hi, const char *const *path, int depth, Box &out)
+struct Box { size_t lo, hi; };
+bool find_box(const FileView &fv, size_t lo, size_t hi, const char *const *path, int depth, Box &out)
 {
+    hi = std::min(hi, fv.f.size());
     while (lo + 8 <= hi) {
-        uint64_t size = be32(&f[lo]);
+        uint64_t size = fv.u32(lo);
         size_t hdr = 8;
-        if (size == 1) { if (lo + 16 > hi) return false; size = be64(&f[lo + 8]); hdr = 16; }
+        if (size == 1) { if (lo + 16 > hi) return false; size = fv.u64(lo + 8); hdr = 16; }
         else if (size == 0) size = hi - lo;
-        if (size < hdr || lo + size > hi) return false;
-        if (std::memcmp(&f[lo + 4], path[0], 4) == 0) {
-            if (depth == 1) { out = Box{be32(&f[lo + 4]), lo + hdr, lo + (size_t)size}; return true; }
-            if (find_box(f, lo + hdr, lo + (size_t)size, path + 1, depth - 1, out)) return true;
+        if (size < hdr || size > hi - lo) return false;
+        if (fv.is(lo + 4, path[0])) {
+            if (depth == 1) { out = Box{lo + hdr, lo + (size_t)size}; return true; }
+            if (find_box(fv, lo + hdr, lo + (size_t)size, path + 1, depth - 1, out)) return true;
         }
         lo += (size_t)size;
     }
@@ -901,45 +916,67 @@ namespace {
 
 void open_tables(lkingest &v)
 {
-    const std::vector<uint8_t> &f = v.file;
+    const FileView fv{v.file};
     Box moov;
     const char *pm[] = {"moov"};
-    if (!find_box(f, 0, f.size(), pm, 1, moov)) throw BadStream("no moov box");
+    if (!find_box(fv, 0, v.file.size(), pm, 1, moov)) throw BadStream("no moov box");
     size_t lo = moov.lo;
     while (lo + 8 <= moov.hi) {
-        const uint64_t size = be32(&f[lo]);
-        if (size < 8 || lo + size > moov.hi) break;
-        if (std::memcmp(&f[lo + 4], "trak", 4) == 0) {
+        const uint64_t size = fv.u32(lo);
+        if (size < 8 || size > moov.hi - lo) break;
+        if (fv.is(lo + 4, "trak")) {
             Box stbl, stsd, b2;
             const char *ps[] = {"mdia", "minf", "stbl"};
             const char *p1[] = {"stsd"}, *p2[] = {"stsz"}, *p3[] = {"stco"}, *p4[] = {"co64"}, *p5[] = {"stsc"}, *p6[] = {"avcC"};
-            if (find_box(f, lo + 8, lo + (size_t)size, ps, 3, stbl) && find_box(f, stbl.lo, stbl.hi, p1, 1, stsd) &&
-                stsd.lo + 16 <= stsd.hi && std::memcmp(&f[stsd.lo + 12], "avc1", 4) == 0) {
-                const size_t entry = stsd.lo + 8, esz = be32(&f[entry]);
+            if (find_box(fv, lo + 8, lo + (size_t)size, ps, 3, stbl) && find_box(fv, stbl.lo, stbl.hi, p1, 1, stsd) && fv.is(stsd.lo + 12, "avc1")) {
+                const size_t entry = stsd.lo + 8, esz = fv.u32(entry);
                 Box avcc;
-                if (!find_box(f, entry + 8 + 78, entry + esz, p6, 1, avcc)) throw BadStream("no avcC box");
-                const uint8_t *c = &f[avcc.lo];
-                v.nls = (c[4] & 3) + 1;
+                if (esz < 86 || esz > stsd.hi - entry || !find_box(fv, entry + 8 + 78, entry + esz, p6, 1, avcc)) throw BadStream("no avcC box");
+                // AVCDecoderConfigurationRecord: every field inside the box
+                auto c = [&](size_t p) { if (avcc.lo + p >= avcc.hi) throw BadStream("avcC too short"); return fv.u8(avcc.lo + p); };
+                v.nls = (c(4) & 3) + 1;
                 size_t p = 6;
-                for (int k = c[5] & 31; k > 0; --k) { const size_t n = ((size_t)c[p] << 8) | c[p + 1]; v.dec.sps = parse_sps(c + p + 2, n); p += 2 + n; }
-                for (int k = c[p++]; k > 0; --k) { const size_t n = ((size_t)c[p] << 8) | c[p + 1]; v.dec.pps = parse_pps(c + p + 2, n); p += 2 + n; }
-                if (!find_box(f, stbl.lo, stbl.hi, p2, 1, b2)) throw BadStream("no stsz box");
-                const uint32_t fixed = be32(&f[b2.lo + 4]), count = be32(&f[b2.lo + 8]);
+                for (int k = c(5) & 31; k > 0; --k) {
+                    const size_t n = ((size_t)c(p) << 8) | c(p + 1);
+                    if (n < 4 || avcc.lo + p + 2 + n > avcc.hi) throw BadStream("avcC: bad parameter-set length");
+                    v.dec.sps = parse_sps(&v.file[avcc.lo + p + 2], n);
+                    p += 2 + n;
+                }
+                int npps = c(p++);
+                for (; npps > 0; --npps) {
+                    const size_t n = ((size_t)c(p) << 8) | c(p + 1);
+                    if (n < 2 || avcc.lo + p + 2 + n > avcc.hi) throw BadStream("avcC: bad parameter-set length");
+                    v.dec.pps = parse_pps(&v.file[avcc.lo + p + 2], n);
+                    p += 2 + n;
+                }
+                if (v.dec.sps.mb_w < 1 || v.dec.sps.mb_h < 1 || v.dec.sps.mb_w > 512 || v.dec.sps.mb_h > 512) throw BadStream("picture size out of range");
+                if (!find_box(fv, stbl.lo, stbl.hi, p2, 1, b2)) throw BadStream("no stsz box");
+                const uint32_t fixed = fv.u32(b2.lo + 4), count = fv.u32(b2.lo + 8);
+                if (count > (1u << 24) || (!fixed && (size_t)count * 4 > b2.hi - b2.lo)) throw BadStream("stsz: bad sample count");
                 std::vector<uint32_t> sizes(count, fixed);
-                if (!fixed) for (uint32_t k = 0; k < count; ++k) sizes[k] = be32(&f[b2.lo + 12 + 4 * (size_t)k]);
+                if (!fixed) for (uint32_t k = 0; k < count; ++k) sizes[k] = fv.u32(b2.lo + 12 + 4 * (size_t)k);
                 std::vector<uint64_t> chunks;
-                if (find_box(f, stbl.lo, stbl.hi, p3, 1, b2)) { const uint32_t n = be32(&f[b2.lo + 4]); for (uint32_t k = 0; k < n; ++k) chunks.push_back(be32(&f[b2.lo + 8 + 4 * (size_t)k])); }
-                else if (find_box(f, stbl.lo, stbl.hi, p4, 1, b2)) { const uint32_t n = be32(&f[b2.lo + 4]); for (uint32_t k = 0; k < n; ++k) chunks.push_back(be64(&f[b2.lo + 8 + 8 * (size_t)k])); }
-                else throw BadStream("no chunk offsets");
-                if (!find_box(f, stbl.lo, stbl.hi, p5, 1, b2)) throw BadStream("no stsc box");
-                const uint32_t nsc = be32(&f[b2.lo + 4]);
+                if (find_box(fv, stbl.lo, stbl.hi, p3, 1, b2)) {
+                    const uint32_t n = fv.u32(b2.lo + 4);
+                    if ((size_t)n * 4 > b2.hi - b2.lo) throw BadStream("stco: bad entry count");
+                    for (uint32_t k = 0; k < n; ++k) chunks.push_back(fv.u32(b2.lo + 8 + 4 * (size_t)k));
+                } else if (find_box(fv, stbl.lo, stbl.hi, p4, 1, b2)) {
+                    const uint32_t n = fv.u32(b2.lo + 4);
+                    if ((size_t)n * 8 > b2.hi - b2.lo) throw BadStream("co64: bad entry count");
+                    for (uint32_t k = 0; k < n; ++k) chunks.push_back(fv.u64(b2.lo + 8 + 8 * (size_t)k));
+                } else throw BadStream("no chunk offsets");
+                if (!find_box(fv, stbl.lo, stbl.hi, p5, 1, b2)) throw BadStream("no stsc box");
+                const uint32_t nsc = fv.u32(b2.lo + 4);
+                if ((size_t)nsc * 12 > b2.hi - b2.lo) throw BadStream("stsc: bad entry count");
+                std::vector<std::pair<uint32_t, uint32_t>> stsc;
+                for (uint32_t s = 0; s < nsc; ++s) stsc.push_back({fv.u32(b2.lo + 8 + 12 * (size_t)s), fv.u32(b2.lo + 12 + 12 * (size_t)s)});
                 size_t k = 0;
-                for (size_t ci = 0; ci < chunks.size(); ++ci) {
+                for (size_t ci = 0; ci < chunks.size() && k < count; ++ci) {
                     uint32_t per = 0;
-                    for (uint32_t s = 0; s < nsc; ++s) if (ci + 1 >= be32(&f[b2.lo + 8 + 12 * (size_t)s])) per = be32(&f[b2.lo + 12 + 12 * (size_t)s]);
+                    for (const auto &e : stsc) if (ci + 1 >= e.first) per = e.second;
                     uint64_t off = chunks[ci];
                     for (uint32_t s = 0; s < per && k < count; ++s, ++k) {
-                        if (off + sizes[k] > f.size()) throw BadStream("sample outside the file");
+                        if (off > v.file.size() || sizes[k] > v.file.size() - off) throw BadStream("sample outside the file");
                         v.samples.push_back({(size_t)off, sizes[k]});
                         off += sizes[k];
                     }

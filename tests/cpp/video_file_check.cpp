@@ -6,7 +6,14 @@
 
 #include "lkingest.hpp"
 
+static int run(int argc, char **argv);
 int main(int argc, char **argv)
+{
+    try { return run(argc, argv); }
+    catch (const std::exception &e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }   // a stream that does not decode: status, not abort
+}
+
+static int run(int argc, char **argv)
 {
     if (argc != 4) { std::fprintf(stderr, "usage: %s in.mp4 out_luma.u8 out_first_bgr.u8\n", argv[0]); return 2; }
     lkflow::VideoFile missing("/nonexistent/file.mp4");

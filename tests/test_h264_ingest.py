@@ -146,3 +146,22 @@ def test_cpp_reader_equals_the_python_decoder(tmp_path):
     f = np.load(FIXTURE)
     assert np.array_equal(np.fromfile(luma, np.uint8).reshape(245, 160, 240), f["Y"])
     assert np.array_equal(np.fromfile(bgr, np.uint8).reshape(160, 240, 3), h.yuv420_to_bgr(f["Y"][:1], f["Cb"][:1], f["Cr"][:1])[0])
+
+
+@pytest.mark.skipif(not os.path.exists(MP4), reason="the reference's pacman.mp4 is not on this machine (GPU box)")
+def test_cpp_reader_under_sanitizers_on_damaged_files(tmp_path):
+    """The reader is fed files: a damaged one must end in a status, not in an out-of-range access.  The decoder and the harness built
+    with -fsanitize=address,undefined: the real file decodes clean, and 60 mutated copies (tools/fuzz_ingest.py: flipped bytes in the
+    sample tables, parameter sets and slice data, truncations, bit flips in the first IDR slice; the builder-side runs did 1500) each end
+    with status 0 or 1 and no sanitizer report."""
+    import subprocess
+    lib = str(tmp_path / "liblkingest_asan.so")
+    exe = str(tmp_path / "vfc_asan")
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+    subprocess.check_call(["g++", "-std=c++20", "-fPIC", "-shared", *san, os.path.join(PKG, "ingest", "h264_ingest.cpp"), "-o", lib])
+    subprocess.check_call(["g++", "-std=c++17", *san, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "video_file_check.cpp"),
+                           "-o", exe, "-L", str(tmp_path), "-llkingest_asan", f"-Wl,-rpath,{tmp_path}"])
+    r = subprocess.run([exe, MP4, str(tmp_path / "l.u8"), str(tmp_path / "b.u8")], capture_output=True, text=True)
+    assert r.returncode == 0 and "frames read: 245" in r.stdout and "Sanitizer" not in r.stderr, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ingest.py"), "11", "60", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CRASH" not in r.stdout, r.stdout[-3000:]
