@@ -562,3 +562,19 @@ def test_reference_video_loop_on_the_real_pacman_frames(gpu_ctx, oracle, torch):
     for p in (0, 3):
         assert tuple(rows[p]) == tuple(oracle.flow_centroid(host(U[p]), host(V[p]), 20.0)), (p, rows[p])
     assert rows[:, 0].max() > 0
+
+
+def test_bench_frame_queue_deadline_keeps_the_headline_line():
+    """The N > 1 bench path when its frame-queue extra gets stuck (rehearsed on the one-GPU box: two ranks over gloo, deadline of one
+    millisecond): rank 0 still prints the complete headline line -- measured before the extra started --, with stream_sharding.error
+    set, and the job ends with status 0 so that a launcher does not discard the measurement; LKFLOW_BENCH_STREAM_EXTRA_FAIL_STATUS=3
+    restores the strict form."""
+    import json
+    import sys
+    base = dict(os.environ, LKFLOW_BENCH_REHEARSE_ONE_GPU="1", MASTER_ADDR="127.0.0.1", LKFLOW_BENCH_STREAM_EXTRA_DEADLINE_S="0.001")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pairs", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    for status in ("0", "3"):
+        out = subprocess.run(cmd, env=dict(base, LKFLOW_BENCH_STREAM_EXTRA_FAIL_STATUS=status), capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == int(status), (status, out.returncode, out.stderr[-2000:])
+        rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert rec["n_gpus"] == 2 and rec["value"] > 0 and "deadline" in rec["stream_sharding"]["error"]
