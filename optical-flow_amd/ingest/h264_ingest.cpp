@@ -44,7 +44,7 @@ struct Bits {
         for (int i = 0; i < k; ++i) { size_t p = pos + i; r = (r << 1) | (p < n ? (d[p >> 3] >> (7 - (p & 7))) & 1 : 0); }
         return r;
     }
-    unsigned ue() { int z = 0; while (bit() == 0) if (++z > 32) throw BadStream("bad Exp-Golomb code"); return (1u << z) - 1 + u(z); }
+    unsigned ue() { int z = 0; while (bit() == 0) if (++z > 31) throw BadStream("bad Exp-Golomb code"); return (1u << z) - 1 + u(z); }
     int se() { unsigned k = ue(); return (k & 1) ? (int)((k + 1) >> 1) : -(int)(k >> 1); }
     int te(int cmax) { return cmax > 1 ? (int)ue() : 1 - (int)bit(); }
     bool more() const { return pos < end; }
@@ -142,6 +142,7 @@ int residual_block(Bits &b, int nC, int max_coeff, int *coef)
         if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
         if (i == t1 && t1 < 3) code += 2;
         const int lv = (code % 2 == 0) ? (code + 2) >> 1 : (-code - 1) >> 1;
+        if (lv < -32768 || lv > 32767) throw BadStream("coefficient level out of range");   // (8-bit video: 16-bit levels; keeps the scaling below in range)
         level[i] = lv;
         if (suffix_len == 0) suffix_len = 1;
         if (std::abs(lv) > (3 << (suffix_len - 1)) && suffix_len < 6) ++suffix_len;
@@ -202,18 +203,21 @@ void luma_dc(const int *coef, int qp, int dc[4][4])
     for (int k = 0; k < 16; ++k) c[ZZ_Y[k]][ZZ_X[k]] = coef[k];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { int s = 0; for (int k = 0; k < 4; ++k) s += H4[i][k] * c[k][j]; t[i][j] = s; }
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { int s = 0; for (int k = 0; k < 4; ++k) s += t[i][k] * H4[k][j]; f[i][j] = s; }
-    const int ls = level_scale(qp % 6, 0, 0);
+    const int64_t ls = level_scale(qp % 6, 0, 0);
     for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-            dc[i][j] = qp >= 36 ? (f[i][j] * ls) << (qp / 6 - 6) : (f[i][j] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+        for (int j = 0; j < 4; ++j) {
+            const int64_t v = qp >= 36 ? (f[i][j] * ls) << (qp / 6 - 6) : (f[i][j] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+            dc[i][j] = (int)std::clamp<int64_t>(v, -(1 << 26), 1 << 26);   // (no conforming stream comes near: keeps a damaged one inside int)
+        }
 }
 
 void chroma_dc(const int *coef, int qpc, int dc[2][2])
 {
     const int c00 = coef[0], c01 = coef[1], c10 = coef[2], c11 = coef[3];
     const int f[2][2] = {{c00 + c01 + c10 + c11, c00 - c01 + c10 - c11}, {c00 + c01 - c10 - c11, c00 - c01 - c10 + c11}};
-    const int ls = level_scale(qpc % 6, 0, 0);
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) dc[i][j] = ((f[i][j] * ls) << (qpc / 6)) >> 5;
+    const int64_t ls = level_scale(qpc % 6, 0, 0);
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) dc[i][j] = (int)std::clamp<int64_t>(((f[i][j] * ls) << (qpc / 6)) >> 5, -(1 << 26), 1 << 26);
 }
 
 // ---------------------------------------------------------------------------------------------- planes and pictures
